@@ -1,0 +1,290 @@
+// Heatmap decode for CenterNet multi-person pose on gfx950.
+//
+// Replaces the reference's ~60-launch torch expression graph
+//   lib/models/decode.py:10-16   (_nms: 3x3 max-pool equality)
+//   lib/models/decode.py:87-115  (_topk_channel / _topk)
+//   lib/models/utils.py:11-25    (_transpose_and_gather_feat: whole-map permute + gather)
+//   lib/models/decode.py:235-308 (multi_pose_decode)
+// with two kernels:
+//   K6 nms_topk_kernel   : one 1024-thread workgroup per (image, heat-map plane).  NMS'd values
+//                          become order-preserving uint32 keys in LDS; a 4-pass 8-bit radix
+//                          select finds the K-th largest key; survivors are compacted and
+//                          bitonic-sorted.  Order = (value desc, flat index asc).
+//   K7 pose_assign_kernel: one workgroup per (image, joint): gathers hps/reg/wh/hp_offset
+//                          straight from the NCHW maps at the K peaks (no whole-map transpose),
+//                          does the K x K nearest-candidate search from LDS, applies the
+//                          reference's acceptance rules and packs dets[B,K,5+3J].
+// All float arithmetic is done in the reference's operation order with FP contraction disabled
+// (this file is compiled with -ffp-contract=off), so on tie-free inputs the output is
+// bit-identical to the reference CPU path.  HBM-bound integer/compare work: no MFMA here.
+#include "common.h"
+
+#define TK_THREADS 1024
+#define TK_WAVES (TK_THREADS / CP_WAVE)
+#define TK_MAX_ELEMS 32768   // keys live in LDS: 128 KiB of the CU's 160 KiB
+#define TK_MAX_K 256
+
+__device__ __forceinline__ uint32_t f2key(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if (u == 0x80000000u) u = 0;  // -0.0 == +0.0 for torch.topk
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key2f(uint32_t k)
+{
+    uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+// ------------------------------------------------------------------------------------------
+// K6: NMS + top-K of one plane group (centre: cat planes of H*W flattened; joints: one plane)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TK_THREADS) void nms_topk_kernel(
+    const float* __restrict__ heat, const float* __restrict__ hm_hp, int cat, int J, int H, int W,
+    int K, int P /* pow2 >= K */, int nmax /* LDS key slots, multiple of 4 */, float* __restrict__ out_scores, int* __restrict__ out_inds)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int ppb = 1 + J;
+    const int b = blockIdx.x / ppb, pl = blockIdx.x % ppb;
+    const int HW = H * W;
+    const float* src;
+    int n;
+    if (pl == 0) { src = heat + (size_t)b * cat * HW; n = cat * HW; }
+    else { src = hm_hp + ((size_t)b * J + (pl - 1)) * HW; n = HW; }
+
+    uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                    // [nmax]
+    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem + (size_t)nmax * 4);  // [TK_MAX_K]
+    uint32_t* hist = reinterpret_cast<uint32_t*>(cand + TK_MAX_K);         // [256]
+    uint32_t* wsum = hist + 256;                                           // [TK_WAVES]
+    uint32_t* sctl = wsum + TK_WAVES;                                      // [4] digit, remaining, cnt_gt
+
+    // ---- phase 1: 3x3 NMS (decode.py:10-16; -inf padding == skip out-of-range) -> keys
+    for (int e = tid; e < n; e += TK_THREADS) {
+        const int c = e / HW, p = e - c * HW;
+        const int y = p / W, x = p - y * W;
+        const float* pp = src + (size_t)c * HW;
+        const float v = pp[p];
+        float m = v;
+        const int y0 = y > 0 ? y - 1 : y, y1 = y < H - 1 ? y + 1 : y;
+        const int x0 = x > 0 ? x - 1 : x, x1 = x < W - 1 ? x + 1 : x;
+        for (int yy = y0; yy <= y1; ++yy)
+            for (int xx = x0; xx <= x1; ++xx) m = fmaxf(m, pp[yy * W + xx]);
+        const float o = (m == v) ? v : v * 0.0f;   // heat * keep
+        keys[e] = f2key(o);
+    }
+    for (int i = tid; i < P; i += TK_THREADS) cand[i] = 0ull;
+    __syncthreads();
+
+    // ---- phase 2: radix select of the K-th largest key (MSB first, 8 bits per pass)
+    uint32_t prefix = 0, pmask = 0;
+    int remaining = K;
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += TK_THREADS) {
+            const int e = base + tid;
+            bool act = false;
+            uint32_t d = 0;
+            if (e < n) {
+                const uint32_t k = keys[e];
+                act = ((k & pmask) == prefix);
+                d = (k >> shift) & 255u;
+            }
+            const unsigned long long am = __ballot(act);
+            if (am) {   // wave-aggregated: NMS zeroes 8/9 of a map, so most lanes share a bin
+                const int first = __ffsll((long long)am) - 1;
+                const uint32_t d0 = __shfl(d, first);
+                const unsigned long long same = __ballot(act && d == d0);
+                if (same == am) { if (lane == first) atomicAdd(&hist[d0], (uint32_t)__popcll(am)); }
+                else if (act) atomicAdd(&hist[d], 1u);
+            }
+        }
+        __syncthreads();
+        if (wid == 0) {
+            // lane l owns bins 255-4l .. 252-4l (descending order)
+            uint32_t h[4], s = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { h[i] = hist[255 - 4 * lane - i]; s += h[i]; }
+            uint32_t inc = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o); if (lane >= o) inc += t; }
+            const uint32_t exc = inc - s;
+            if (exc < (uint32_t)remaining && (uint32_t)remaining <= inc) {
+                uint32_t acc = exc;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (acc < (uint32_t)remaining && (uint32_t)remaining <= acc + h[i]) {
+                        sctl[0] = 255 - 4 * lane - i;
+                        sctl[1] = remaining - acc;
+                    }
+                    acc += h[i];
+                }
+            }
+        }
+        __syncthreads();
+        prefix |= sctl[0] << shift;
+        pmask |= 255u << shift;
+        remaining = (int)sctl[1];
+        __syncthreads();
+    }
+    const uint32_t T = prefix;          // K-th largest key
+    const int need_eq = remaining;      // how many keys == T to take (lowest indices first)
+    const int cnt_gt = K - need_eq;
+
+    // ---- phase 3: compaction.  key > T: any slot in [0,cnt_gt).  key == T: index-ordered rank.
+    if (tid == 0) sctl[2] = 0;
+    // each wave owns a contiguous index range so that equal keys are ranked by index
+    const int per_wave = ((n + TK_WAVES - 1) / TK_WAVES + 63) & ~63;
+    const int wbeg = wid * per_wave, wend = min(n, wbeg + per_wave);
+    uint32_t my_eq = 0;
+    for (int base = wbeg; base < wend; base += 64) {
+        const int e = base + lane;
+        const bool eq = (e < wend) && (keys[e] == T);
+        my_eq += (uint32_t)__popcll(__ballot(eq));
+    }
+    if (lane == 0) wsum[wid] = my_eq;
+    __syncthreads();
+    uint32_t eq_base = 0;
+    for (int w = 0; w < wid; ++w) eq_base += wsum[w];
+    for (int base = wbeg; base < wend; base += 64) {
+        const int e = base + lane;
+        uint32_t k = 0;
+        bool gt = false, eq = false;
+        if (e < wend) { k = keys[e]; gt = k > T; eq = (k == T); }
+        const unsigned long long em = __ballot(eq);
+        if (eq) {
+            const uint32_t rank = eq_base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
+            if (rank < (uint32_t)need_eq)
+                cand[cnt_gt + rank] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)e);
+        }
+        eq_base += (uint32_t)__popcll(em);
+        if (gt) {
+            const uint32_t slot = atomicAdd(&sctl[2], 1u);
+            cand[slot] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)e);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 4: bitonic sort of P candidates, descending (value desc, index asc)
+    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += TK_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = cand[i], c = cand[ixj];
+                    const bool desc = ((i & k2) == 0);
+                    if (desc ? (a < c) : (a > c)) { cand[i] = c; cand[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < K; i += TK_THREADS) {
+        const unsigned long long c = cand[i];
+        out_scores[(size_t)blockIdx.x * K + i] = key2f((uint32_t)(c >> 32));
+        out_inds[(size_t)blockIdx.x * K + i] = (int)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K7: gather + keypoint-to-person assignment + pack  (decode.py:244-307)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pose_assign_kernel(
+    const float* __restrict__ wh, const float* __restrict__ kps, const float* __restrict__ reg,
+    const float* __restrict__ hp_offset, const float* __restrict__ scores,
+    const int* __restrict__ inds, int J, int H, int W, int K, float* __restrict__ dets)
+{
+    __shared__ float s_hx[TK_MAX_K], s_hy[TK_MAX_K], s_hs[TK_MAX_K];
+    const int b = blockIdx.x / J, j = blockIdx.x % J;
+    const int HW = H * W, ppb = 1 + J, D = 5 + 3 * J;
+    const float* jsc = scores + ((size_t)b * ppb + 1 + j) * K;
+    const int* jin = inds + ((size_t)b * ppb + 1 + j) * K;
+
+    for (int m = threadIdx.x; m < K; m += blockDim.x) {
+        const float s = jsc[m];
+        const int ind = jin[m];
+        float hy = (float)(ind / W), hx = (float)(ind % W);       // decode.py:92-93
+        if (hp_offset) {                                          // :272-277 (2-ch map shared by joints)
+            hx = hx + hp_offset[((size_t)b * 2 + 0) * HW + ind];
+            hy = hy + hp_offset[((size_t)b * 2 + 1) * HW + ind];
+        } else { hx = hx + 0.5f; hy = hy + 0.5f; }
+        const float mk = (s > 0.1f) ? 1.0f : 0.0f;               // :282
+        s_hs[m] = (1.0f - mk) * -1.0f + mk * s;                   // :283
+        s_hy[m] = (1.0f - mk) * -10000.0f + mk * hy;              // :284
+        s_hx[m] = (1.0f - mk) * -10000.0f + mk * hx;              // :285
+    }
+    __syncthreads();
+
+    const float* csc = scores + (size_t)b * ppb * K;
+    const int* cin = inds + (size_t)b * ppb * K;
+    for (int k = threadIdx.x; k < K; k += blockDim.x) {
+        const int p = cin[k] % HW;                                // decode.py:104 (class plane dropped)
+        const float ys = (float)(p / W), xs = (float)(p % W);
+        const float kx = kps[((size_t)b * 2 * J + 2 * j) * HW + p] + xs;       // :246 integer peak coords
+        const float ky = kps[((size_t)b * 2 * J + 2 * j + 1) * HW + p] + ys;   // :247
+        float cx, cy;
+        if (reg) { cx = xs + reg[((size_t)b * 2 + 0) * HW + p]; cy = ys + reg[((size_t)b * 2 + 1) * HW + p]; }
+        else { cx = xs + 0.5f; cy = ys + 0.5f; }
+        const float w = wh[((size_t)b * 2 + 0) * HW + p], h = wh[((size_t)b * 2 + 1) * HW + p];
+        const float l = cx - w / 2.0f, t = cy - h / 2.0f, r = cx + w / 2.0f, bt = cy + h / 2.0f;  // :261-264
+
+        float best = 0.f;
+        int bi = 0;
+        for (int m = 0; m < K; ++m) {                             // :286-289, first minimum
+            const float dx = kx - s_hx[m], dy = ky - s_hy[m];
+            const float d = __fsqrt_rn(dx * dx + dy * dy);
+            if (m == 0 || d < best) { best = d; bi = m; }
+        }
+        const float ss = s_hs[bi], sx = s_hx[bi], sy = s_hy[bi];
+        const bool rej = (sx < l) || (sx > r) || (sy < t) || (sy > bt) || (ss < 0.1f) ||
+                         (best > fmaxf(bt - t, r - l) * 0.3f);    // :300-302
+        const float mk = rej ? 1.0f : 0.0f;
+        float* row = dets + ((size_t)b * K + k) * D;
+        row[5 + 2 * j] = (1.0f - mk) * sx + mk * kx;              // :304
+        row[5 + 2 * j + 1] = (1.0f - mk) * sy + mk * ky;
+        row[5 + 2 * J + j] = ss;                                  // :307 (score emitted even if rejected)
+        if (j == 0) { row[0] = l; row[1] = t; row[2] = r; row[3] = bt; row[4] = csc[k]; }
+    }
+}
+
+extern "C" int cp_decode_workspace_bytes(int B, int J, int K, size_t* scores_bytes, size_t* inds_bytes)
+{
+    if (scores_bytes) *scores_bytes = (size_t)B * (1 + J) * K * sizeof(float);
+    if (inds_bytes) *inds_bytes = (size_t)B * (1 + J) * K * sizeof(int);
+    return 0;
+}
+
+extern "C" int cp_multi_pose_decode_f32(const float* heat, const float* wh, const float* kps,
+                                        const float* reg, const float* hm_hp, const float* hp_offset,
+                                        int B, int cat, int J, int H, int W, int K, float* dets,
+                                        float* ws_scores, int* ws_inds, void* stream)
+{
+    CP_CHECK_ARG(heat && wh && kps && dets && ws_scores && ws_inds, "multi_pose_decode: null pointer");
+    CP_CHECK_ARG(hm_hp != nullptr,
+                 "multi_pose_decode: hm_hp is required (the reference raises NameError without it, decode.py:307)");
+    CP_CHECK_ARG(B > 0 && cat > 0 && J > 0 && H > 0 && W > 0, "multi_pose_decode: bad shape");
+    CP_CHECK_ARG(K > 0 && K <= TK_MAX_K, "multi_pose_decode: K=%d out of range (1..%d)", K, TK_MAX_K);
+    CP_CHECK_ARG((long long)cat * H * W <= TK_MAX_ELEMS, "multi_pose_decode: cat*H*W=%lld exceeds the LDS-resident limit %d",
+                 (long long)cat * H * W, TK_MAX_ELEMS);
+    CP_CHECK_ARG(H * W >= K, "multi_pose_decode: K=%d larger than the map (%d)", K, H * W);
+    int P = 1;
+    while (P < K) P <<= 1;
+    const int nmax = ((cat * H * W > H * W ? cat * H * W : H * W) + 3) & ~3;
+    const size_t lds = (size_t)nmax * 4 + TK_MAX_K * 8 + 256 * 4 + TK_WAVES * 4 + 16;
+    static size_t lds_reserved = 0;   // one device per process (one rank per GPU)
+    if (lds > lds_reserved) {
+        hipError_t e = hipFuncSetAttribute((const void*)nms_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { cp_set_error("decode: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return 2; }
+        lds_reserved = lds;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(nms_topk_kernel, dim3(B * (1 + J)), dim3(TK_THREADS), lds, s, heat, hm_hp, cat, J, H, W, K, P,
+                       nmax, ws_scores, ws_inds);
+    CP_CHECK_LAUNCH("nms_topk_kernel");
+    hipLaunchKernelGGL(pose_assign_kernel, dim3(B * J), dim3(128), 0, s, wh, kps, reg, hp_offset, ws_scores, ws_inds, J,
+                       H, W, K, dets);
+    CP_CHECK_LAUNCH("pose_assign_kernel");
+    return 0;
+}
