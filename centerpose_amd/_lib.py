@@ -50,6 +50,17 @@ def ptr(t):
     return c_void_p(t.data_ptr())
 
 
+def vptr(t):
+    """Device pointer of a strided NHWC *view* (layout is validated by the caller)."""
+    if t is None:
+        return c_void_p(0)
+    if not t.is_cuda:
+        raise CenterposeHipError("centerpose_amd runs on the GPU only (got a %s tensor)" % t.device)
+    if t.dtype != torch.float32:
+        raise CenterposeHipError("float32 tensor expected (got %s)" % t.dtype)
+    return c_void_p(t.data_ptr())
+
+
 def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 

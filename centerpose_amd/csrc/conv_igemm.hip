@@ -1,0 +1,267 @@
+// Fused convolution kernels (implicit GEMM on fp32 MFMA) -- see igemm.h for the core.
+//
+// Replaces, for the inference hot path, what the reference gets from cuDNN + separate
+// BatchNorm / ReLU / add / cat kernels:
+//   nn.Conv2d + BatchNorm2d(eval) + ReLU     pose_dla_dcn.py:272-282, msra_resnet.py:82-102, ...
+//   BasicBlock / Bottleneck residual add      pose_dla_dcn.py:43-57, msra_resnet.py:82-102
+//   Root: torch.cat -> 1x1 conv -> BN -> ReLU pose_dla_dcn.py:155-163  (concat-free: up to 4 sources)
+//   dense ConvTranspose2d(k4,s2,p1)           msra_resnet.py:168-193   (4 sub-pixel 2x2 convs)
+//   KeypointHead convs (+bias, +sigmoid)      lib/models/heads/keypoint.py:14-42, multi_pose.py:35-37
+// A-producers: NHWC im2col gather (any kh,kw,stride,pad) and a scalar gather for the 3-channel
+// NCHW network input (7x7 / 3x3 stems).
+#include "igemm.h"
+
+// per-thread description of the output pixels whose A rows this thread stages
+struct PixSlot {
+    int boff;   // b*H*W (input pixel index of the image origin), -1 if m >= M
+    int iy0, ix0;
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, bool STEM>
+__global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a)
+{
+    using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As0 = smem;
+    float* Bs0 = smem + 2 * IG_BK * T::LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int NT = a.ldw / BN;
+    const int tile = ig_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = tile % NT, mt = tile / NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wid / WAVES_N) * T::WM, wn0 = (wid % WAVES_N) * T::WN;
+    const int HoWo = a.Ho * a.Wo;
+
+    typename IgAcc<MF>::type acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < IgAcc<MF>::N; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.K / IG_BK;
+    float4 br[T::B_SLOTS];
+
+    if constexpr (!STEM) {
+        // ---------------- NHWC im2col producer: thread -> (pixel, 4-channel quad) -------------
+        const int q = tid & 3;
+        PixSlot ps[T::A_SLOTS];
+#pragma unroll
+        for (int s = 0; s < T::A_SLOTS; ++s) {
+            const int m = m0 + (tid >> 2) + s * 64;
+            if (m < a.M) {
+                const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
+                ps[s].boff = b * a.H * a.W;
+                ps[s].iy0 = oy * a.sy - a.py;
+                ps[s].ix0 = ox * a.sx - a.px;
+            } else { ps[s].boff = -1; ps[s].iy0 = 0; ps[s].ix0 = 0; }
+        }
+        float4 ar[T::A_SLOTS];
+        // k-walk state (wave-uniform): tap (ky,kx), source index, channel offset inside the source
+        int ky = 0, kx = 0, si = 0, cl = 0;
+
+        auto load_a = [&]() {
+            const float* sp = a.src[si];
+            const int ld = a.srcLd[si];
+#pragma unroll
+            for (int s = 0; s < T::A_SLOTS; ++s) {
+                const int iy = ps[s].iy0 + ky, ix = ps[s].ix0 + kx;
+                const bool ok = ps[s].boff >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                ar[s] = ok ? *reinterpret_cast<const float4*>(sp + (size_t)(ps[s].boff + iy * a.W + ix) * ld + cl + q * 4)
+                           : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        auto advance = [&]() {
+            cl += IG_BK;
+            if (cl >= a.srcC[si]) { cl = 0; if (++si >= a.nsrc) { si = 0; if (++kx >= a.kw) { kx = 0; ++ky; } } }
+        };
+        auto store_a = [&](float* As) {
+#pragma unroll
+            for (int s = 0; s < T::A_SLOTS; ++s) {
+                const int pl = (tid >> 2) + s * 64;
+                As[(q * 4 + 0) * T::LDA + pl] = ar[s].x;
+                As[(q * 4 + 1) * T::LDA + pl] = ar[s].y;
+                As[(q * 4 + 2) * T::LDA + pl] = ar[s].z;
+                As[(q * 4 + 3) * T::LDA + pl] = ar[s].w;
+            }
+        };
+
+        load_a(); advance();
+        ig_load_b<T, BN>(a, 0, n0, tid, br);
+        store_a(As0);
+        ig_store_b<T, BN>(Bs0, tid, br);
+        __syncthreads();
+        int cur = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+            const bool more = ks + 1 < nk;
+            if (more) { load_a(); advance(); ig_load_b<T, BN>(a, (ks + 1) * IG_BK, n0, tid, br); }
+            ig_compute<T, MF>(As0 + cur * IG_BK * T::LDA, Bs0 + cur * IG_BK * T::LDB, wm0, wn0, lane, acc);
+            if (more) {
+                store_a(As0 + (cur ^ 1) * IG_BK * T::LDA);
+                ig_store_b<T, BN>(Bs0 + (cur ^ 1) * IG_BK * T::LDB, tid, br);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    } else {
+        // ---------------- stem producer: NCHW input, tiny C (3): k = (c*kh + ky)*kw + kx ------
+        // thread -> one pixel column of the tile (consecutive lanes = consecutive x: coalesced),
+        // 16*BM/256 scalar gathers per k-step, written straight into As[k][m] (no transpose).
+        constexpr int EPT = IG_BK * BM / IG_THREADS;       // elements per thread per k-step
+        constexpr int KPT = EPT / (BM / 64 > 4 ? 4 : 1);   // (unused helper, kept simple below)
+        (void)KPT;
+        const float* sp = a.src[0];
+        const int C = a.srcC[0], khw = a.kh * a.kw, Kreal = C * khw;
+        // thread handles pixel pl = tid % BM and k rows kq, kq + (256/BM), ...
+        const int pl = tid % BM, kq = tid / BM;
+        constexpr int KSTRIDE = IG_THREADS / BM;           // 1 (BM=256), 2 (BM=128), 4 (BM=64)
+        constexpr int NPER = IG_BK / KSTRIDE;
+        const int m = m0 + pl;
+        int boff = -1, iy0 = 0, ix0 = 0;
+        if (m < a.M) {
+            const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
+            boff = b * C * a.H * a.W;
+            iy0 = oy * a.sy - a.py;
+            ix0 = ox * a.sx - a.px;
+        }
+        float ar[NPER];
+        auto load_a = [&](int k0) {
+#pragma unroll
+            for (int e = 0; e < NPER; ++e) {
+                const int k = k0 + kq + e * KSTRIDE;
+                const int c = k / khw, t = k - c * khw, ky = t / a.kw, kx = t - ky * a.kw;
+                const int iy = iy0 + ky, ix = ix0 + kx;
+                const bool ok = boff >= 0 && k < Kreal && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                ar[e] = ok ? sp[(size_t)boff + ((size_t)c * a.H + iy) * a.W + ix] : 0.f;
+            }
+        };
+        auto store_a = [&](float* As) {
+#pragma unroll
+            for (int e = 0; e < NPER; ++e) As[(kq + e * KSTRIDE) * T::LDA + pl] = ar[e];
+        };
+        load_a(0);
+        ig_load_b<T, BN>(a, 0, n0, tid, br);
+        store_a(As0);
+        ig_store_b<T, BN>(Bs0, tid, br);
+        __syncthreads();
+        int cur = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+            const bool more = ks + 1 < nk;
+            if (more) { load_a((ks + 1) * IG_BK); ig_load_b<T, BN>(a, (ks + 1) * IG_BK, n0, tid, br); }
+            ig_compute<T, MF>(As0 + cur * IG_BK * T::LDA, Bs0 + cur * IG_BK * T::LDB, wm0, wn0, lane, acc);
+            if (more) {
+                store_a(As0 + (cur ^ 1) * IG_BK * T::LDA);
+                ig_store_b<T, BN>(Bs0 + (cur ^ 1) * IG_BK * T::LDB, tid, br);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, bool STEM>
+static int launch_conv(const ConvArgs& a, hipStream_t s)
+{
+    using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
+    auto kern = igemm_conv_kernel<BM, BN, WAVES_M, WAVES_N, MF, STEM>;
+    if (a.ldw % BN != 0) { cp_set_error("conv2d: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
+    const int smem = a.outNCHW ? T::SMEM : T::MAIN_BYTES;
+    static bool attr = false;
+    if (!attr && smem > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
+        attr = true;
+    }
+    const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
+    return 0;
+}
+
+// Public descriptor (mirrors ConvArgs with plain ints; see include/centerpose_hip.h)
+struct cp_conv_desc {
+    int nsrc;
+    int srcC[4];
+    int srcLd[4];
+    int B, H, W;
+    int Ho, Wo;
+    int kh, kw, sy, sx, py, px;
+    int K, ldw;
+    int Cout;
+    int resLd;
+    int outLd;
+    int outNCHW;
+    int OH, OW, osy, osx, ooy, oox;
+    int act;
+    int inNCHW;   // 1: src[0] is the NCHW network input with srcC[0] (<16) channels (stem path)
+    int tile;     // 0 = auto; otherwise BM*1000+BN of a specific instantiation (tuning / tests)
+};
+
+extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale,
+                             const float* shift, const float* res, float* out, void* stream)
+{
+    CP_CHECK_ARG(d && src && w && scale && shift && out, "conv2d: null pointer");
+    CP_CHECK_ARG(d->nsrc >= 1 && d->nsrc <= IG_MAX_SRC, "conv2d: nsrc=%d", d->nsrc);
+    CP_CHECK_ARG(d->K % IG_BK == 0 && d->K > 0, "conv2d: K=%d must be a positive multiple of 16", d->K);
+    CP_CHECK_ARG(d->ldw % 16 == 0 && d->ldw >= d->Cout, "conv2d: ldw=%d (Cout=%d)", d->ldw, d->Cout);
+    ConvArgs a;
+    int ctot = 0;
+    for (int i = 0; i < IG_MAX_SRC; ++i) {
+        a.src[i] = i < d->nsrc ? src[i] : nullptr;
+        a.srcC[i] = i < d->nsrc ? d->srcC[i] : 0;
+        a.srcLd[i] = i < d->nsrc ? d->srcLd[i] : 0;
+        if (i < d->nsrc) {
+            CP_CHECK_ARG(src[i] != nullptr, "conv2d: src[%d] is null", i);
+            ctot += d->srcC[i];
+            if (!d->inNCHW)
+                CP_CHECK_ARG(d->srcC[i] % 16 == 0 && d->srcLd[i] % 4 == 0 && d->srcLd[i] >= d->srcC[i],
+                             "conv2d: NHWC source %d needs C%%16==0, ld%%4==0 (C=%d ld=%d)", i, d->srcC[i], d->srcLd[i]);
+        }
+    }
+    if (d->inNCHW) CP_CHECK_ARG(d->nsrc == 1 && d->K >= ctot * d->kh * d->kw, "conv2d: bad stem descriptor");
+    else CP_CHECK_ARG(d->K == ctot * d->kh * d->kw, "conv2d: K=%d != kh*kw*Ctot=%d", d->K, ctot * d->kh * d->kw);
+    a.nsrc = d->nsrc; a.Ctot = ctot;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo;
+    a.M = d->B * d->Ho * d->Wo;
+    a.kh = d->kh; a.kw = d->kw; a.sy = d->sy; a.sx = d->sx; a.py = d->py; a.px = d->px;
+    a.K = d->K; a.w = w; a.ldw = d->ldw; a.scale = scale; a.shift = shift;
+    a.res = res; a.resLd = d->resLd; a.out = out; a.outLd = d->outLd; a.Cout = d->Cout;
+    a.outNCHW = d->outNCHW; a.OH = d->OH; a.OW = d->OW; a.osy = d->osy; a.osx = d->osx; a.ooy = d->ooy; a.oox = d->oox;
+    a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1;
+    CP_CHECK_ARG(a.M > 0 && (long long)d->B * d->H * d->W < (1ll << 31), "conv2d: bad problem size");
+    CP_CHECK_ARG(!(res && d->outNCHW), "conv2d: residual with NCHW output is not supported");
+    hipStream_t s = (hipStream_t)stream;
+
+    int tile = d->tile;
+    if (tile == 0) {
+        // heuristic: N tile from the padded channel count, M tile from how many blocks fill 256 CUs
+        if (d->ldw % 64 != 0) tile = (d->ldw % 32 == 0) ? 128032 : 256016;
+        else {
+            const long long blocks128 = (long long)cp_cdiv(a.M, 128) * (d->ldw / 64);
+            if (d->ldw % 128 == 0 && (long long)cp_cdiv(a.M, 128) * (d->ldw / 128) >= 1024) tile = 128128;
+            else tile = blocks128 >= 768 ? 128064 : 64064;
+        }
+    }
+    int rc = 0;
+    if (d->inNCHW) {
+        switch (tile) {
+            case 256016: rc = launch_conv<256, 16, 4, 1, 16, true>(a, s); break;
+            case 128032: rc = launch_conv<128, 32, 4, 1, 32, true>(a, s); break;
+            case 128064: case 64064: case 128128: rc = launch_conv<128, 64, 2, 2, 32, true>(a, s); break;
+            default: CP_CHECK_ARG(false, "conv2d: unknown stem tile %d", tile);
+        }
+    } else {
+        switch (tile) {
+            case 256016: rc = launch_conv<256, 16, 4, 1, 16, false>(a, s); break;
+            case 128032: rc = launch_conv<128, 32, 4, 1, 32, false>(a, s); break;
+            case 128064: rc = launch_conv<128, 64, 2, 2, 32, false>(a, s); break;
+            case 64064: rc = launch_conv<64, 64, 2, 2, 32, false>(a, s); break;
+            case 128128: rc = launch_conv<128, 128, 2, 2, 32, false>(a, s); break;
+            default: CP_CHECK_ARG(false, "conv2d: unknown tile %d", tile);
+        }
+    }
+    if (rc) return rc;
+    CP_CHECK_LAUNCH("igemm_conv_kernel");
+    return 0;
+}

@@ -1,0 +1,207 @@
+// Fused modulated deformable convolution (DCNv2) forward for gfx950.
+//
+// Reference: lib/models/backbones/DCNv2/src/cuda/dcn_v2_cuda.cu:42-172 materialises
+// columns[B, C*9, Ho*Wo] in HBM with modulated_deformable_im2col_gpu_kernel
+// (dcn_v2_im2col_cuda.cu:125-195, bilinear :25-54) and then runs two batched cuBLAS SGEMMs
+// (bias broadcast :123-137, out += W * columns :149-163).  Here the sampled, mask-modulated
+// A-tile goes straight from registers into LDS and is consumed by fp32 MFMA: the `columns`
+// round trip (37.7 MB per image for a 64-channel 128x128 layer) never exists, and the
+// DeformConv wrapper's BatchNorm + ReLU (pose_dla_dcn.py:345-348) fold into the epilogue.
+//
+// Semantics reproduced exactly (Appendix B.3 of SURVEY.md):
+//   h_im = oy*sy - py + ky*dil + dy_k ; sample valid iff h_im > -1 && w_im > -1 && h_im < H && w_im < W
+//   4-corner bilinear with per-corner zeroing (h_low >= 0, w_high <= W-1, ...), value * mask_k.
+// Per block: the (pixel, tap) sampling records {clamped corner base, dx, dy bits, 4 weights*mask}
+// are computed once into LDS (9 * BM * 20 B); each k-step then issues 4 corner float4 loads per
+// (pixel, 4-channel quad), blends in registers and stages the result k-major like a plain conv.
+#include "igemm.h"
+
+#define DCN_MAX_TAPS 9
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF>
+__global__ __launch_bounds__(IG_THREADS) void dcn_igemm_kernel(const ConvArgs a)
+{
+    using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // records first, GEMM staging after; the NCHW epilogue reuses the whole region from the base
+    float4* s_w = reinterpret_cast<float4*>(smem);                 // [taps][BM] corner weights * mask
+    int* s_code = reinterpret_cast<int*>(s_w + DCN_MAX_TAPS * BM); // [taps][BM] base | dx<<29 | dy<<30
+    float* As0 = smem + DCN_MAX_TAPS * BM * 5;
+    float* Bs0 = As0 + 2 * IG_BK * T::LDA;
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int NT = a.ldw / BN;
+    const int tile = ig_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = tile % NT, mt = tile / NT;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int wm0 = (wid / WAVES_N) * T::WM, wn0 = (wid % WAVES_N) * T::WN;
+    const int HoWo = a.Ho * a.Wo;
+    const int ntap = a.kh * a.kw;
+    const int C = a.srcC[0], ld = a.srcLd[0];
+    const float* __restrict__ x = a.src[0];
+
+    // ---- sampling records for every (tap, pixel) of this tile
+    for (int idx = tid; idx < ntap * BM; idx += IG_THREADS) {
+        const int t = idx / BM, pl = idx - t * BM;
+        const int m = m0 + pl;
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        int code = 0;
+        if (m < a.M) {
+            const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
+            const float* omp = a.om + (size_t)m * a.omLd;
+            const int ky = t / a.kw, kx = t - ky * a.kw;
+            const float offh = omp[2 * t], offw = omp[2 * t + 1];
+            float mk = omp[a.omMaskOff + t];
+            if (a.omSigmoid) mk = 1.0f / (1.0f + __expf(-mk));
+            const float h_im = (float)(oy * a.sy - a.py + ky * a.dily) + offh;
+            const float w_im = (float)(ox * a.sx - a.px + kx * a.dilx) + offw;
+            if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
+                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                const int h_high = h_low + 1, w_high = w_low + 1;
+                const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+                const float hh = 1.f - lh, hw = 1.f - lw;
+                const bool t_ok = h_low >= 0, b_ok = h_high <= a.H - 1, l_ok = w_low >= 0, r_ok = w_high <= a.W - 1;
+                w4.x = (t_ok && l_ok) ? hh * hw * mk : 0.f;
+                w4.y = (t_ok && r_ok) ? hh * lw * mk : 0.f;
+                w4.z = (b_ok && l_ok) ? lh * hw * mk : 0.f;
+                w4.w = (b_ok && r_ok) ? lh * lw * mk : 0.f;
+                const int yl = t_ok ? h_low : 0, xl = l_ok ? w_low : 0;     // clamped, always in range
+                const int dy = (t_ok && b_ok) ? 1 : 0, dx = (l_ok && r_ok) ? 1 : 0;
+                code = (b * a.H * a.W + yl * a.W + xl) | (dx << 29) | (dy << 30);
+                // when the top/left corner is out of range the record's base already IS the
+                // bottom/right corner; its weight must then come from the matching slot:
+                if (!t_ok) { w4.x = w4.z; w4.y = w4.w; w4.z = 0.f; w4.w = 0.f; }
+                if (!l_ok) { w4.x = w4.y; w4.z = w4.w; w4.y = 0.f; w4.w = 0.f; }
+            }
+        }
+        s_w[idx] = w4;
+        s_code[idx] = code;
+    }
+
+    typename IgAcc<MF>::type acc[T::TM][T::TN];
+#pragma unroll
+    for (int i = 0; i < T::TM; ++i)
+#pragma unroll
+        for (int j = 0; j < T::TN; ++j)
+#pragma unroll
+            for (int r = 0; r < IgAcc<MF>::N; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = a.K / IG_BK;
+    const int q = tid & 3;
+    float4 br[T::B_SLOTS];
+    float4 c00[T::A_SLOTS], c01[T::A_SLOTS], c10[T::A_SLOTS], c11[T::A_SLOTS], wq[T::A_SLOTS];
+    int tap = 0, cl = 0;
+    __syncthreads();
+
+    auto load_a = [&]() {
+#pragma unroll
+        for (int s = 0; s < T::A_SLOTS; ++s) {
+            const int pl = (tid >> 2) + s * 64;
+            const int code = s_code[tap * BM + pl];
+            wq[s] = s_w[tap * BM + pl];
+            const int base = code & 0x1FFFFFFF, dx = (code >> 29) & 1, dy = (code >> 30) & 1;
+            const float* p0 = x + (size_t)base * ld + cl + q * 4;
+            c00[s] = *reinterpret_cast<const float4*>(p0);
+            c01[s] = *reinterpret_cast<const float4*>(p0 + dx * ld);
+            c10[s] = *reinterpret_cast<const float4*>(p0 + (size_t)dy * a.W * ld);
+            c11[s] = *reinterpret_cast<const float4*>(p0 + (size_t)dy * a.W * ld + dx * ld);
+        }
+    };
+    auto advance = [&]() { cl += IG_BK; if (cl >= C) { cl = 0; ++tap; } };
+    auto store_a = [&](float* As) {
+#pragma unroll
+        for (int s = 0; s < T::A_SLOTS; ++s) {
+            const int pl = (tid >> 2) + s * 64;
+            const float4 w = wq[s];
+            As[(q * 4 + 0) * T::LDA + pl] = w.x * c00[s].x + w.y * c01[s].x + w.z * c10[s].x + w.w * c11[s].x;
+            As[(q * 4 + 1) * T::LDA + pl] = w.x * c00[s].y + w.y * c01[s].y + w.z * c10[s].y + w.w * c11[s].y;
+            As[(q * 4 + 2) * T::LDA + pl] = w.x * c00[s].z + w.y * c01[s].z + w.z * c10[s].z + w.w * c11[s].z;
+            As[(q * 4 + 3) * T::LDA + pl] = w.x * c00[s].w + w.y * c01[s].w + w.z * c10[s].w + w.w * c11[s].w;
+        }
+    };
+
+    load_a(); advance();
+    ig_load_b<T, BN>(a, 0, n0, tid, br);
+    store_a(As0);
+    ig_store_b<T, BN>(Bs0, tid, br);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        if (more) { load_a(); advance(); ig_load_b<T, BN>(a, (ks + 1) * IG_BK, n0, tid, br); }
+        ig_compute<T, MF>(As0 + cur * IG_BK * T::LDA, Bs0 + cur * IG_BK * T::LDB, wm0, wn0, lane, acc);
+        if (more) {
+            store_a(As0 + (cur ^ 1) * IG_BK * T::LDA);
+            ig_store_b<T, BN>(Bs0 + (cur ^ 1) * IG_BK * T::LDB, tid, br);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+    ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF>
+static int launch_dcn(const ConvArgs& a, hipStream_t s)
+{
+    using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
+    auto kern = dcn_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MF>;
+    if (a.ldw % BN != 0) { cp_set_error("dcn: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
+    const int main_bytes = T::MAIN_BYTES + DCN_MAX_TAPS * BM * 20;
+    const int smem = (a.outNCHW && T::EPI_BYTES > main_bytes) ? T::EPI_BYTES : main_bytes;
+    static bool attr = false;
+    if (!attr && smem > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        attr = true;
+    }
+    const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
+    return 0;
+}
+
+struct cp_dcn_desc {
+    int B, H, W, C, srcLd;     // input NHWC
+    int Ho, Wo;
+    int kh, kw, sy, sx, py, px, dily, dilx;
+    int K, ldw, Cout;
+    int omLd, omSigmoid;       // om[B,Ho,Wo,omLd]: 2k = dy, 2k+1 = dx, 2*kh*kw + k = mask (logit if omSigmoid)
+    int outLd, outNCHW, act;
+    int tile;
+};
+
+extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* om, const float* w, const float* scale,
+                             const float* shift, float* out, void* stream)
+{
+    CP_CHECK_ARG(d && x && om && w && scale && shift && out, "dcn_v2: null pointer");
+    CP_CHECK_ARG(d->kh * d->kw <= DCN_MAX_TAPS && d->kh * d->kw > 0, "dcn_v2: at most %d taps", DCN_MAX_TAPS);
+    CP_CHECK_ARG(d->C % 16 == 0 && d->srcLd % 4 == 0 && d->srcLd >= d->C, "dcn_v2: C%%16==0, ld%%4==0 required");
+    CP_CHECK_ARG(d->K == d->kh * d->kw * d->C, "dcn_v2: K=%d != kh*kw*C", d->K);
+    CP_CHECK_ARG(d->ldw % 16 == 0 && d->ldw >= d->Cout, "dcn_v2: ldw=%d Cout=%d", d->ldw, d->Cout);
+    CP_CHECK_ARG(d->omLd >= 3 * d->kh * d->kw, "dcn_v2: omLd=%d too small", d->omLd);
+    CP_CHECK_ARG((long long)d->B * d->H * d->W < (1ll << 29), "dcn_v2: input too large");
+    ConvArgs a;
+    for (int i = 0; i < IG_MAX_SRC; ++i) { a.src[i] = nullptr; a.srcC[i] = 0; a.srcLd[i] = 0; }
+    a.src[0] = x; a.srcC[0] = d->C; a.srcLd[0] = d->srcLd; a.nsrc = 1; a.Ctot = d->C;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Ho = d->Ho; a.Wo = d->Wo; a.M = d->B * d->Ho * d->Wo;
+    a.kh = d->kh; a.kw = d->kw; a.sy = d->sy; a.sx = d->sx; a.py = d->py; a.px = d->px;
+    a.K = d->K; a.w = w; a.ldw = d->ldw; a.scale = scale; a.shift = shift; a.res = nullptr; a.resLd = 0;
+    a.out = out; a.outLd = d->outLd; a.Cout = d->Cout; a.outNCHW = d->outNCHW;
+    a.OH = d->Ho; a.OW = d->Wo; a.osy = a.osx = 1; a.ooy = a.oox = 0; a.act = d->act;
+    a.om = om; a.omLd = d->omLd; a.omMaskOff = 2 * d->kh * d->kw; a.omSigmoid = d->omSigmoid;
+    a.dily = d->dily; a.dilx = d->dilx;
+    hipStream_t s = (hipStream_t)stream;
+    int tile = d->tile;
+    if (tile == 0) {
+        if (d->ldw % 64 != 0) tile = (d->ldw % 32 == 0) ? 128032 : 0;
+        else tile = ((long long)cp_cdiv(a.M, 128) * (d->ldw / 64) >= 768) ? 128064 : 64064;
+    }
+    int rc = 0;
+    switch (tile) {
+        case 128032: rc = launch_dcn<128, 32, 4, 1, 32>(a, s); break;
+        case 128064: rc = launch_dcn<128, 64, 2, 2, 32>(a, s); break;
+        case 64064: rc = launch_dcn<64, 64, 2, 2, 32>(a, s); break;
+        default: CP_CHECK_ARG(false, "dcn_v2: unsupported tile %d (ldw=%d)", tile, d->ldw);
+    }
+    if (rc) return rc;
+    CP_CHECK_LAUNCH("dcn_igemm_kernel");
+    return 0;
+}

@@ -1,0 +1,200 @@
+// Bandwidth-bound NHWC helpers around the GEMM kernels (float4 over channels, grid-stride).
+//   max-pool                        nn.MaxPool2d       pose_dla_dcn.py:197-198, msra_resnet.py:123
+//   depthwise bilinear deconv + add IDAUp up_* + add   pose_dla_dcn.py:360-377 (groups=o, k=2f, s=f, p=f/2)
+//   nearest-upsample sum (+ReLU)    HRNet fuse layers  pose_higher_hrnet.py:217-235
+//   layout transforms               NCHW <-> NHWC (drop-in dcn_v2_forward, tests)
+//   flip-test merge                 multi_pose.py:45-53 + models/utils.py:27-47 (device side, no numpy bounce)
+#include "common.h"
+
+#define EW_THREADS 256
+static inline int ew_grid(long long n) { long long g = (n + EW_THREADS - 1) / EW_THREADS; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
+
+__global__ void maxpool_nhwc_kernel(const float* __restrict__ in, int inLd, float* __restrict__ out, int outLd, int B,
+                                    int H, int W, int C4, int Ho, int Wo, int k, int s, int p)
+{
+    const long long total = (long long)B * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long pix = i / C4;
+        const int ox = (int)(pix % Wo); pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * s - p + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * s - p + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)(b * H + iy) * W + ix) * inLd + c4 * 4);
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(out + ((size_t)(b * Ho + oy) * Wo + ox) * outLd + c4 * 4) = m;
+    }
+}
+
+extern "C" int cp_maxpool2d_nhwc_f32(const float* in, int inLd, float* out, int outLd, int B, int H, int W, int C, int k,
+                                     int s, int p, void* stream)
+{
+    CP_CHECK_ARG(in && out && C % 4 == 0 && inLd % 4 == 0 && outLd % 4 == 0, "maxpool: C, ld must be multiples of 4");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    const long long total = (long long)B * Ho * Wo * (C / 4);
+    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, out,
+                       outLd, B, H, W, C / 4, Ho, Wo, k, s, p);
+    CP_CHECK_LAUNCH("maxpool_nhwc_kernel");
+    return 0;
+}
+
+// out[b,oy,ox,c] = add[b,oy,ox,c] + sum_{ky,kx} in[b,iy,ix,c] * w[(ky*k+kx)][c],  oy = iy*f - p + ky
+__global__ void dw_deconv_add_kernel(const float* __restrict__ in, int inLd, const float* __restrict__ w,
+                                     const float* __restrict__ add, int addLd, float* __restrict__ out, int outLd, int B,
+                                     int H, int W, int C4, int f, int p)
+{
+    const int k = 2 * f, Ho = H * f, Wo = W * f, C = C4 * 4;
+    const long long total = (long long)B * Ho * Wo * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long pix = i / C4;
+        const int ox = (int)(pix % Wo); pix /= Wo;
+        const int oy = (int)(pix % Ho);
+        const int b = (int)(pix / Ho);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        // ky = oy + p - iy*f must lie in [0, k): two candidate input rows / columns
+        const int ry = (oy + p) % f, rx = (ox + p) % f;
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty) {
+            const int ky = ry + ty * f, iy = (oy + p - ky) / f;
+            if (oy + p - ky < 0 || iy >= H) continue;
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx) {
+                const int kx = rx + tx * f, ix = (ox + p - kx) / f;
+                if (ox + p - kx < 0 || ix >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)(b * H + iy) * W + ix) * inLd + c4 * 4);
+                const float4 ww = *reinterpret_cast<const float4*>(w + (size_t)(ky * k + kx) * C + c4 * 4);
+                acc.x += v.x * ww.x; acc.y += v.y * ww.y; acc.z += v.z * ww.z; acc.w += v.w * ww.w;
+            }
+        }
+        const size_t opix = (size_t)(b * Ho + oy) * Wo + ox;
+        if (add) {
+            const float4 r = *reinterpret_cast<const float4*>(add + opix * addLd + c4 * 4);
+            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+        }
+        *reinterpret_cast<float4*>(out + opix * outLd + c4 * 4) = acc;
+    }
+}
+
+extern "C" int cp_dw_deconv_add_nhwc_f32(const float* in, int inLd, const float* w, const float* add, int addLd, float* out,
+                                         int outLd, int B, int H, int W, int C, int f, void* stream)
+{
+    CP_CHECK_ARG(in && w && out && C % 4 == 0 && inLd % 4 == 0 && outLd % 4 == 0 && (!add || addLd % 4 == 0),
+                 "dw_deconv_add: C, ld must be multiples of 4");
+    CP_CHECK_ARG(f >= 1, "dw_deconv_add: f=%d", f);
+    const long long total = (long long)B * H * f * W * f * (C / 4);
+    hipLaunchKernelGGL(dw_deconv_add_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, w, add,
+                       addLd, out, outLd, B, H, W, C / 4, f, f / 2);
+    CP_CHECK_LAUNCH("dw_deconv_add_kernel");
+    return 0;
+}
+
+// out = act( sum_i nearest_up(src_i, 2^sh_i) ), all NHWC with C channels; out is [B,H,W,C]
+struct SumUpArgs { const float* src[4]; int ld[4]; int sh[4]; int n; };
+__global__ void sum_up_kernel(SumUpArgs a, float* __restrict__ out, int outLd, int B, int H, int W, int C4, int relu)
+{
+    const long long total = (long long)B * H * W * C4;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        long long pix = i / C4;
+        const int x = (int)(pix % W); pix /= W;
+        const int y = (int)(pix % H);
+        const int b = (int)(pix / H);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < a.n; ++j) {
+            const int sh = a.sh[j], hs = H >> sh, ws = W >> sh;
+            const float4 v = *reinterpret_cast<const float4*>(a.src[j] + ((size_t)(b * hs + (y >> sh)) * ws + (x >> sh)) * a.ld[j] + c4 * 4);
+            if (j == 0) acc = v;
+            else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        }
+        if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+        *reinterpret_cast<float4*>(out + ((size_t)(b * H + y) * W + x) * outLd + c4 * 4) = acc;
+    }
+}
+
+extern "C" int cp_sum_up_nhwc_f32(int n, const float* const* src, const int* ld, const int* shift, float* out, int outLd,
+                                  int B, int H, int W, int C, int relu, void* stream)
+{
+    CP_CHECK_ARG(n >= 1 && n <= 4 && src && ld && shift && out && C % 4 == 0, "sum_up: bad arguments");
+    SumUpArgs a;
+    for (int i = 0; i < 4; ++i) { a.src[i] = i < n ? src[i] : nullptr; a.ld[i] = i < n ? ld[i] : 0; a.sh[i] = i < n ? shift[i] : 0; }
+    a.n = n;
+    const long long total = (long long)B * H * W * (C / 4);
+    hipLaunchKernelGGL(sum_up_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, a, out, outLd, B, H, W,
+                       C / 4, relu);
+    CP_CHECK_LAUNCH("sum_up_kernel");
+    return 0;
+}
+
+// ---- layout transforms (32x32 LDS tile transpose over (C, HW)) -------------------------------
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int outLd, int cOff)
+{
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        t[r][tx] = (c < C && p < HW) ? in[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (c < C && p < HW) out[((size_t)b * HW + p) * outLd + cOff + c] = t[tx][r];
+    }
+}
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int inLd, int cOff, float* __restrict__ out, int C, int HW)
+{
+    __shared__ float t[32][33];
+    const int b = blockIdx.z, c0 = blockIdx.y * 32, p0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        t[r][tx] = (c < C && p < HW) ? in[((size_t)b * HW + p) * inLd + cOff + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) out[((size_t)b * C + c) * HW + p] = t[tx][r];
+    }
+}
+
+extern "C" int cp_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int outLd, int cOff, void* stream)
+{
+    CP_CHECK_ARG(in && out && outLd >= cOff + C, "nchw_to_nhwc: bad arguments");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(cp_cdiv(HW, 32), cp_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, in, out,
+                       C, HW, outLd, cOff);
+    CP_CHECK_LAUNCH("nchw_to_nhwc_kernel");
+    return 0;
+}
+extern "C" int cp_nhwc_to_nchw_f32(const float* in, int inLd, int cOff, float* out, int B, int C, int H, int W, void* stream)
+{
+    CP_CHECK_ARG(in && out && inLd >= cOff + C, "nhwc_to_nchw: bad arguments");
+    const int HW = H * W;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(cp_cdiv(HW, 32), cp_cdiv(C, 32), B), dim3(256), 0, (hipStream_t)stream, in, inLd,
+                       cOff, out, C, HW);
+    CP_CHECK_LAUNCH("nhwc_to_nchw_kernel");
+    return 0;
+}
+
+extern "C" int cp_fill_f32(float* p, float v, long long n, void* stream);
+__global__ void fill_kernel(float* p, float v, long long n)
+{
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) p[i] = v;
+}
+extern "C" int cp_fill_f32(float* p, float v, long long n, void* stream)
+{
+    CP_CHECK_ARG(p && n >= 0, "fill: bad arguments");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(fill_kernel, dim3(ew_grid(n)), dim3(EW_THREADS), 0, (hipStream_t)stream, p, v, n);
+    CP_CHECK_LAUNCH("fill_kernel");
+    return 0;
+}

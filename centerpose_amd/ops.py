@@ -1,0 +1,226 @@
+"""Thin Python wrappers over the C-ABI kernels (torch tensors in, device pointers out).
+
+Activations are NHWC float32 tensors ``[B,H,W,C]`` (views with a larger pixel stride are allowed:
+only ``stride(2)`` -- floats between pixels -- is passed down).  Weight packing (BN folding,
+K-major repack) happens once at plan time, on the device, with plain torch ops.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+BN_EPS = 1e-5  # nn.BatchNorm2d default (reference never overrides it)
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("nsrc",)] + [("srcC", ctypes.c_int * 4), ("srcLd", ctypes.c_int * 4)] + \
+        [(n, ctypes.c_int) for n in ("B", "H", "W", "Ho", "Wo", "kh", "kw", "sy", "sx", "py", "px", "K", "ldw", "Cout",
+                                     "resLd", "outLd", "outNCHW", "OH", "OW", "osy", "osx", "ooy", "oox", "act",
+                                     "inNCHW", "tile")]
+
+
+class DcnDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "H", "W", "C", "srcLd", "Ho", "Wo", "kh", "kw", "sy", "sx", "py", "px",
+                                            "dily", "dilx", "K", "ldw", "Cout", "omLd", "omSigmoid", "outLd",
+                                            "outNCHW", "act", "tile")]
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+def pad_cols(t, ldw):
+    """[K, Co] -> [K, ldw] zero padded, contiguous."""
+    K, Co = t.shape
+    if Co == ldw:
+        return t.contiguous()
+    out = torch.zeros((K, ldw), dtype=t.dtype, device=t.device)
+    out[:, :Co] = t
+    return out
+
+
+def pad_vec(v, ldw, fill=0.0):
+    out = torch.full((ldw,), fill, dtype=torch.float32, device=v.device)
+    out[: v.numel()] = v
+    return out
+
+
+def ldw_for(cout):
+    """padded output-channel count: multiple of 16 / 32 / 64 (N tile of the kernel variant)."""
+    if cout <= 16:
+        return 16
+    if cout <= 32:
+        return 32
+    return round_up(cout, 64)
+
+
+def pack_conv_weight(w, stem=False):
+    """torch conv weight [Co,Ci,kh,kw] -> K-major [K, ldw].
+    NHWC producer: k = (ky*kw + kx)*Ci + c.   Stem (NCHW input): k = (c*kh + ky)*kw + kx, K padded to 16."""
+    Co, Ci, kh, kw = w.shape
+    if stem:
+        wp = w.reshape(Co, Ci * kh * kw).t()
+        K = round_up(Ci * kh * kw, 16)
+        if K != wp.shape[0]:
+            wp = torch.cat([wp, torch.zeros((K - wp.shape[0], Co), dtype=w.dtype, device=w.device)], 0)
+    else:
+        wp = w.permute(2, 3, 1, 0).reshape(kh * kw * Ci, Co)
+    return pad_cols(wp.float(), ldw_for(Co))
+
+
+def fold_bn(cout, bn=None, bias=None, device=None):
+    """(scale, shift) so that y = conv*scale + shift == BN(conv + bias)  (eval mode)."""
+    if bn is not None:
+        g, b, mean, var = bn
+        scale = g / torch.sqrt(var + BN_EPS)
+        shift = b - mean * scale
+        if bias is not None:
+            shift = shift + bias * scale
+    else:
+        device = bias.device if bias is not None else device
+        scale = torch.ones(cout, dtype=torch.float32, device=device)
+        shift = bias.clone() if bias is not None else torch.zeros(cout, dtype=torch.float32, device=device)
+    ldw = ldw_for(cout)
+    return pad_vec(scale.float(), ldw, 0.0), pad_vec(shift.float(), ldw, 0.0)
+
+
+def _ld(t):
+    assert t.dim() == 4 and t.stride(3) == 1 and t.stride(1) == t.shape[2] * t.stride(2) and \
+        t.stride(0) == t.shape[1] * t.stride(1), "NHWC tensor with dense pixels expected"
+    return t.stride(2)
+
+
+def conv2d(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=ACT_NONE, res=None, out_nchw=False,
+           in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0):
+    """Fused conv: out = act((sum_src conv(src)) * scale + shift [+ res]).
+
+    srcs: list of NHWC tensors (concatenated along C) or one NCHW tensor when in_nchw.
+    out : NHWC [B,OH,OW,>=cout] (or NCHW [B,cout,OH,OW] when out_nchw).
+    out_scatter = (osy, osx, ooy, oox): output pixel (oy*osy+ooy, ox*osx+oox) (sub-pixel deconv)."""
+    L = _lib.lib()
+    d = ConvDesc()
+    d.nsrc = len(srcs)
+    if in_nchw:
+        x = srcs[0]
+        B, C, H, W = x.shape
+        d.srcC[0], d.srcLd[0] = C, 0
+        assert x.is_contiguous()
+    else:
+        B, H, W, _ = srcs[0].shape
+        for i, s in enumerate(srcs):
+            assert s.shape[:3] == srcs[0].shape[:3]
+            d.srcC[i], d.srcLd[i] = s.shape[3], _ld(s)
+    py, px = pad_yx if pad_yx is not None else (pad, pad)
+    if Ho is None:
+        Ho = (H + 2 * py - kh) // stride + 1
+        Wo = (W + 2 * px - kw) // stride + 1
+    d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
+    d.kh, d.kw, d.sy, d.sx, d.py, d.px = kh, kw, stride, stride, py, px
+    d.K, d.ldw, d.Cout = wp.shape[0], wp.shape[1], cout
+    d.resLd = _ld(res) if res is not None else 0
+    d.outNCHW = 1 if out_nchw else 0
+    if out_nchw:
+        d.OH, d.OW, d.outLd = out.shape[2], out.shape[3], 0
+        assert out.is_contiguous() and out.shape[1] == cout
+    else:
+        d.OH, d.OW, d.outLd = out.shape[1], out.shape[2], _ld(out)
+    d.osy, d.osx, d.ooy, d.oox = out_scatter if out_scatter is not None else (1, 1, 0, 0)
+    d.act, d.inNCHW, d.tile = act, 1 if in_nchw else 0, tile
+    ptrs = (ctypes.c_void_p * 4)(*[_lib.vptr(s).value for s in srcs] + [None] * (4 - len(srcs)))
+    rc = L.cp_conv2d_f32(ctypes.byref(d), ptrs, _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift),
+                         _lib.vptr(res), _lib.vptr(out), _lib.stream())
+    _lib.check(rc, "cp_conv2d_f32")
+    return out
+
+
+def dcn_v2(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, pad=1, dil=1, om_sigmoid=True,
+           act=ACT_NONE, out_nchw=False, tile=0):
+    """Fused DCNv2: x NHWC [B,H,W,C]; om NHWC [B,Ho,Wo,>=3*kh*kw] (dy,dx pairs then mask)."""
+    L = _lib.lib()
+    B, H, W, C = x.shape
+    d = DcnDesc()
+    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
+    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    assert om.shape[:3] == (B, Ho, Wo)
+    d.B, d.H, d.W, d.C, d.srcLd, d.Ho, d.Wo = B, H, W, C, _ld(x), Ho, Wo
+    d.kh, d.kw, d.sy, d.sx, d.py, d.px, d.dily, d.dilx = kh, kw, stride, stride, pad, pad, dil, dil
+    d.K, d.ldw, d.Cout = wp.shape[0], wp.shape[1], cout
+    d.omLd, d.omSigmoid = _ld(om), 1 if om_sigmoid else 0
+    d.outNCHW = 1 if out_nchw else 0
+    d.outLd = 0 if out_nchw else _ld(out)
+    d.act, d.tile = act, tile
+    rc = L.cp_dcn_v2_f32(ctypes.byref(d), _lib.vptr(x), _lib.vptr(om), _lib.ptr(wp), _lib.ptr(scale),
+                         _lib.ptr(shift), _lib.vptr(out), _lib.stream())
+    _lib.check(rc, "cp_dcn_v2_f32")
+    return out
+
+
+def maxpool2d(x, out, k, s, p):
+    B, H, W, C = x.shape
+    rc = _lib.lib().cp_maxpool2d_nhwc_f32(_lib.vptr(x), _ld(x), _lib.vptr(out), _ld(out), B, H, W, C, k, s, p,
+                                          _lib.stream())
+    _lib.check(rc, "cp_maxpool2d_nhwc_f32")
+    return out
+
+
+def pack_dw_deconv_weight(w):
+    """depthwise ConvTranspose2d weight [C,1,k,k] -> [k*k, C]"""
+    C, _, k, _ = w.shape
+    return w.reshape(C, k * k).t().contiguous().float()
+
+
+def dw_deconv_add(x, wk, add, out, f):
+    B, H, W, C = x.shape
+    rc = _lib.lib().cp_dw_deconv_add_nhwc_f32(_lib.vptr(x), _ld(x), _lib.ptr(wk), _lib.vptr(add),
+                                              _ld(add) if add is not None else 0, _lib.vptr(out), _ld(out), B, H, W, C,
+                                              f, _lib.stream())
+    _lib.check(rc, "cp_dw_deconv_add_nhwc_f32")
+    return out
+
+
+def sum_up(srcs, shifts, out, relu):
+    B, H, W, C = out.shape
+    n = len(srcs)
+    ptrs = (ctypes.c_void_p * 4)(*[_lib.vptr(s).value for s in srcs] + [None] * (4 - n))
+    lds = (ctypes.c_int * 4)(*[_ld(s) for s in srcs] + [0] * (4 - n))
+    shs = (ctypes.c_int * 4)(*list(shifts) + [0] * (4 - n))
+    rc = _lib.lib().cp_sum_up_nhwc_f32(n, ptrs, lds, shs, _lib.vptr(out), _ld(out), B, H, W, C, 1 if relu else 0,
+                                       _lib.stream())
+    _lib.check(rc, "cp_sum_up_nhwc_f32")
+    return out
+
+
+def nchw_to_nhwc(x, out=None, c_off=0):
+    B, C, H, W = x.shape
+    if out is None:
+        out = torch.empty((B, H, W, C), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().cp_nchw_to_nhwc_f32(_lib.ptr(_lib.f32(x.contiguous())), _lib.vptr(out), B, C, H, W, _ld(out), c_off,
+                                        _lib.stream())
+    _lib.check(rc, "cp_nchw_to_nhwc_f32")
+    return out
+
+
+def nhwc_to_nchw(x, C=None, c_off=0):
+    B, H, W, Cx = x.shape
+    C = Cx if C is None else C
+    out = torch.empty((B, C, H, W), dtype=torch.float32, device=x.device)
+    rc = _lib.lib().cp_nhwc_to_nchw_f32(_lib.vptr(x), _ld(x), c_off, _lib.ptr(out), B, C, H, W, _lib.stream())
+    _lib.check(rc, "cp_nhwc_to_nchw_f32")
+    return out
+
+
+def pack_deconv4_subpixel(w, py, px):
+    """ConvTranspose2d(k=4, s=2, p=1) weight [Ci,Co,4,4] -> packed 2x2 conv weight for output
+    parity (py, px): out[2q+py] = sum_t in[q - (1-py) + t] * w[ky(t)],  ky(t) = 3 - py - 2t... see below.
+
+    oy = 2*iy - 1 + ky.  py = 0: ky in {3 (iy=q-1), 1 (iy=q)}; py = 1: ky in {2 (iy=q), 0 (iy=q+1)}.
+    With conv padding (1-py) the tap t (iy = q - (1-py) + t) uses ky = 3 - py - 2t... i.e.
+    py=0: t=0 -> 3, t=1 -> 1;  py=1: t=0 -> 2, t=1 -> 0."""
+    Ci, Co = w.shape[:2]
+    kys = [3 - py - 2 * t for t in range(2)]
+    kxs = [3 - px - 2 * t for t in range(2)]
+    sub = w[:, :, kys][:, :, :, kxs]                      # [Ci,Co,2,2] indexed by (ty,tx)
+    wp = sub.permute(2, 3, 0, 1).reshape(4 * Ci, Co)      # k = (ty*2+tx)*Ci + c
+    return pad_cols(wp.float().contiguous(), ldw_for(Co))

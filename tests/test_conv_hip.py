@@ -1,0 +1,210 @@
+"""GPU: fused conv / DCNv2 / pooling / upsampling kernels (through the C ABI) against plain
+torch-CPU fp32 references of the same op and the scalar C DCN oracle.
+Tolerance: fp32 in / fp32 accumulate on MFMA -> |err| <= 2e-4 * max|ref| (summation order only)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _close(out, ref, tol=2e-4):
+    out, ref = out.detach().cpu().double(), ref.detach().cpu().double()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    err = (out - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert err <= tol * scale, "max err %.3e (scale %.3e)" % (err, scale)
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous().cuda()
+
+
+def _rand_bn(g, c):
+    return (torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1,
+            torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5)
+
+
+def _ref_bn(y, bn):
+    gm, b, m, v = bn
+    return F.batch_norm(y, m, v, gm, b, False, 0.0, 1e-5)
+
+
+@pytest.mark.parametrize("cin,cout,k,s,p,hw,tile", [
+    (32, 64, 3, 1, 1, (20, 28), 0), (16, 32, 3, 2, 1, (33, 17), 0), (64, 128, 1, 1, 0, (9, 9), 0),
+    (16, 16, 3, 1, 1, (40, 24), 256016), (32, 32, 3, 1, 1, (16, 16), 128032), (64, 64, 3, 1, 1, (16, 16), 128064),
+    (64, 64, 3, 1, 1, (16, 16), 64064), (48, 128, 3, 1, 1, (24, 24), 128128), (128, 27, 3, 1, 1, (16, 16), 0),
+    (256, 512, 3, 2, 1, (8, 8), 0), (32, 48, 3, 1, 1, (12, 12), 256016),
+])
+def test_conv_bn_relu_residual(cin, cout, k, s, p, hw, tile):
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    B, (H, W) = 3, hw
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bn = _rand_bn(g, cout)
+    ref = _ref_bn(F.conv2d(x, w, None, s, p), bn)
+    res = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref + res)
+    wp = ops.pack_conv_weight(w.cuda())
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    Ho, Wo = ref.shape[2:]
+    out = torch.empty(B, Ho, Wo, cout, device="cuda")
+    ops.conv2d([_nhwc(x)], wp, sc, sh, out, kh=k, kw=k, stride=s, pad=p, cout=cout, act=ops.ACT_RELU,
+               res=_nhwc(res), tile=tile)
+    _close(out.permute(0, 3, 1, 2), ref)
+
+
+def test_conv_concat_sources_and_channel_views():
+    """Root: cat -> 1x1 conv (pose_dla_dcn.py:155-163) without materialising the cat; sources may be
+    channel slices of wider tensors (pixel stride > C)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 10, 14
+    xs = [torch.randn(B, c, H, W, generator=g) for c in (64, 32, 16, 48)]
+    w = torch.randn(80, 160, 1, 1, generator=g) * 0.1
+    bias = torch.randn(80, generator=g)
+    ref = F.relu(F.conv2d(torch.cat(xs, 1), w, bias))
+    wide = torch.randn(B, H, W, 96, generator=g).cuda()          # source 1 lives inside a wider buffer
+    wide[..., 32:64] = _nhwc(xs[1])
+    srcs = [_nhwc(xs[0]), wide[..., 32:64], _nhwc(xs[2]), _nhwc(xs[3])]
+    sc, sh = ops.fold_bn(80, None, bias.cuda())
+    out = torch.empty(B, H, W, 80, device="cuda")
+    ops.conv2d(srcs, ops.pack_conv_weight(w.cuda()), sc, sh, out, kh=1, kw=1, cout=80, act=ops.ACT_RELU)
+    _close(out.permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("cout,k,s,p,hw,tile", [(16, 7, 1, 3, (40, 36), 0), (64, 7, 2, 3, (37, 41), 0),
+                                                (64, 3, 2, 1, (32, 32), 0), (32, 7, 1, 3, (24, 24), 0)])
+def test_stem_nchw_input(cout, k, s, p, hw, tile):
+    """network input is NCHW float32 with 3 channels (base_detector.py:53-58)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(cout + k)
+    x = torch.randn(2, 3, *hw, generator=g)
+    w = torch.randn(cout, 3, k, k, generator=g) * 0.1
+    bn = _rand_bn(g, cout)
+    ref = F.relu(_ref_bn(F.conv2d(x, w, None, s, p), bn))
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    out = torch.empty(2, ref.shape[2], ref.shape[3], cout, device="cuda")
+    ops.conv2d([x.cuda()], ops.pack_conv_weight(w.cuda(), stem=True), sc, sh, out, kh=k, kw=k, stride=s, pad=p,
+               cout=cout, act=ops.ACT_RELU, in_nchw=True, tile=tile)
+    _close(out.permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("cout,act", [(1, 2), (2, 0), (34, 0), (17, 2)])
+def test_head_1x1_nchw_output(cout, act):
+    """KeypointHead final 1x1 conv (+bias) writing the reference's NCHW output, hm/hm_hp sigmoided
+    (keypoint.py:14-42, multi_pose.py:35-37)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(cout)
+    x = torch.randn(2, 64, 12, 20, generator=g)
+    w = torch.randn(cout, 64, 1, 1, generator=g) * 0.2
+    b = torch.randn(cout, generator=g)
+    ref = F.conv2d(x, w, b)
+    if act == 2:
+        ref = torch.sigmoid(ref)
+    sc, sh = ops.fold_bn(cout, None, b.cuda())
+    out = torch.empty(2, cout, 12, 20, device="cuda")
+    ops.conv2d([_nhwc(x)], ops.pack_conv_weight(w.cuda()), sc, sh, out, kh=1, kw=1, cout=cout, act=act, out_nchw=True)
+    _close(out, ref, 1e-5 if act == 2 else 2e-4)
+
+
+def test_dense_deconv_as_subpixel_convs():
+    """ConvTranspose2d(k4,s2,p1) (msra_resnet.py:168-193) == 4 interleaved 2x2 convs."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(3)
+    B, C, Co, H, W = 2, 32, 64, 9, 11
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, Co, 4, 4, generator=g) * 0.1
+    bn = _rand_bn(g, Co)
+    ref = F.relu(_ref_bn(F.conv_transpose2d(x, w, None, 2, 1), bn))
+    sc, sh = ops.fold_bn(Co, tuple(t.cuda() for t in bn))
+    out = torch.empty(B, 2 * H, 2 * W, Co, device="cuda")
+    xg = _nhwc(x)
+    for py_ in range(2):
+        for px_ in range(2):
+            wp = ops.pack_deconv4_subpixel(w.cuda(), py_, px_)
+            ops.conv2d([xg], wp, sc, sh, out, kh=2, kw=2, stride=1, pad=0, pad_yx=(1 - py_, 1 - px_), cout=Co,
+                       act=ops.ACT_RELU, Ho=H, Wo=W, out_scatter=(2, 2, py_, px_))
+    _close(out.permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("k,s,p", [(2, 2, 0), (3, 2, 1)])
+def test_maxpool(k, s, p):
+    from centerpose_amd import ops
+    x = torch.randn(2, 16, 13, 18)
+    ref = F.max_pool2d(x, k, s, p)
+    out = torch.empty(2, ref.shape[2], ref.shape[3], 16, device="cuda")
+    ops.maxpool2d(_nhwc(x), out, k, s, p)
+    assert torch.equal(out.permute(0, 3, 1, 2).cpu(), ref)
+
+
+@pytest.mark.parametrize("f", [2, 4])
+def test_dw_deconv_add(f):
+    """IDAUp: up_i(proj(x)) + layers[i-1] (pose_dla_dcn.py:371-377)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(f)
+    x = torch.randn(2, 32, 7, 9, generator=g)
+    w = torch.randn(32, 1, 2 * f, 2 * f, generator=g)
+    add = torch.randn(2, 32, 7 * f, 9 * f, generator=g)
+    ref = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=32) + add
+    out = torch.empty(2, 7 * f, 9 * f, 32, device="cuda")
+    ops.dw_deconv_add(_nhwc(x), ops.pack_dw_deconv_weight(w.cuda()), _nhwc(add), out, f)
+    _close(out.permute(0, 3, 1, 2), ref, 1e-5)
+
+
+def test_sum_up():
+    from centerpose_amd import ops
+    a, b, c = torch.randn(2, 32, 16, 24), torch.randn(2, 32, 8, 12), torch.randn(2, 32, 4, 6)
+    ref = F.relu(a + F.interpolate(b, scale_factor=2, mode="nearest") + F.interpolate(c, scale_factor=4, mode="nearest"))
+    out = torch.empty(2, 16, 24, 32, device="cuda")
+    ops.sum_up([_nhwc(a), _nhwc(b), _nhwc(c)], [0, 1, 2], out, True)
+    _close(out.permute(0, 3, 1, 2), ref, 1e-6)
+
+
+def _dcn_case(seed, B, C, Co, H, W, big_offsets):
+    r = np.random.RandomState(seed)
+    x = r.randn(B, C, H, W).astype(np.float32)
+    w = (r.randn(Co, C, 3, 3) / (3 * C ** 0.5)).astype(np.float32)
+    b = r.randn(Co).astype(np.float32)
+    off = (r.randn(B, 18, H, W) * (4.0 if big_offsets else 1.0)).astype(np.float32)
+    if big_offsets:                     # far out-of-range and exactly-on-boundary samples
+        off[0, :, 0, 0] = 3 * H
+        off[0, :, 1, 1] = -3 * H
+        off[-1, 0::2, 2, 2] = -1.0      # h_im == integer boundary rows
+        off[-1, 1::2, 2, 3] = W
+    m = r.rand(B, 9, H, W).astype(np.float32)
+    return x, w, b, off, m
+
+
+@pytest.mark.parametrize("C,Co,H,W,big,tile", [(16, 64, 12, 10, True, 0), (64, 64, 16, 16, False, 128064),
+                                               (32, 32, 9, 13, True, 128032), (128, 128, 8, 8, False, 64064)])
+def test_dcn_v2_vs_scalar_oracle(C, Co, H, W, big, tile):
+    from centerpose_amd import ops
+    from oracle import dcn as odcn
+    x, w, b, off, m = _dcn_case(C + H, 2, C, Co, H, W, big)
+    ref = odcn.dcn_v2_forward_c(x, w, b, off, m)
+    om = torch.zeros(2, H, W, 32)
+    om[..., :18] = torch.from_numpy(off).permute(0, 2, 3, 1)
+    om[..., 18:27] = torch.from_numpy(m).permute(0, 2, 3, 1)
+    sc, sh = ops.fold_bn(Co, None, torch.from_numpy(b).cuda())
+    out = torch.empty(2, H, W, Co, device="cuda")
+    ops.dcn_v2(_nhwc(torch.from_numpy(x)), om.cuda(), ops.pack_conv_weight(torch.from_numpy(w).cuda()), sc, sh, out,
+               cout=Co, om_sigmoid=False, tile=tile)
+    _close(out.permute(0, 3, 1, 2), torch.from_numpy(ref), 1e-4)
+
+
+def test_dcn_zero_offset_identity():
+    """The reference's only known-answer check (DCNv2/test.py:31-66): zero offsets, mask 0.5 =>
+    2 * DCN(x) == conv(x)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 10, 10, generator=g)
+    w = torch.randn(32, 16, 3, 3, generator=g) * 0.1
+    om = torch.zeros(2, 10, 10, 32)
+    om[..., 18:27] = 0.5
+    sc, sh = ops.fold_bn(32, None, torch.zeros(32).cuda())
+    out = torch.empty(2, 10, 10, 32, device="cuda")
+    ops.dcn_v2(_nhwc(x), om.cuda(), ops.pack_conv_weight(w.cuda()), sc, sh, out, cout=32, om_sigmoid=False)
+    _close(2 * out.permute(0, 3, 1, 2), F.conv2d(x, w, None, 1, 1), 1e-5)
