@@ -1,0 +1,236 @@
+"""Ahead-of-time inference plan: checkpoint -> static schedule of fused HIP launches.
+
+At construction the network graph (nets.py) is walked once: BatchNorm is folded into per-channel
+scale/shift, weights are repacked K-major on the device, every activation gets a pre-allocated
+NHWC buffer and each launch becomes a closure over raw tensors.  ``forward`` then only replays
+the closures (optionally from a captured hipGraph), so there is no Python graph walking, no
+allocation and no host synchronisation on the hot path.
+
+Replaces ``BackBoneWithHead.forward`` (lib/models/model.py:57-59) for dla_34 / res_50 / hrnet.
+"""
+import torch
+
+from . import _lib, nets, ops
+from .nets import Act
+
+
+def normalize_state_dict(sd):
+    """load_model's key fix-up (lib/models/model.py:76-80): strip a leading 'module.'."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("module") and not k.startswith("module_list"):
+            k = k[7:]
+        out[k] = v
+    return out
+
+
+class PlanBuilder(nets.Graph):
+    def __init__(self, sd, B, device, sigmoid_heads=True):
+        super().__init__()
+        self.sd, self.B, self.dev = sd, B, device
+        self.sigmoid_heads = sigmoid_heads
+        self.launches = []      # (kind, name, flops_per_batch, fn)
+        self.bytes_alloc = 0
+        self._pool_cache = {}
+        self.outputs = None
+
+    # -- helpers ------------------------------------------------------------------------------
+    def buf(self, H, W, C):
+        t = torch.empty((self.B, H, W, C), dtype=torch.float32, device=self.dev)
+        self.bytes_alloc += t.numel() * 4
+        return Act(H, W, C, t)
+
+    def w(self, key):
+        return self.sd[key].to(self.dev, torch.float32)
+
+    def bn(self, name):
+        return tuple(self.w("%s.%s" % (name, s)) for s in ("weight", "bias", "running_mean", "running_var"))
+
+    def add(self, kind, name, flops, fn):
+        self.launches.append((kind, name, flops * self.B, fn))
+
+    # -- emit hooks ---------------------------------------------------------------------------
+    def emit_conv(self, xs, conv, bn, bias, co, k, stride, pad, relu, res, stem):
+        x = xs[0]
+        Ho, Wo = (x.H + 2 * pad - k) // stride + 1, (x.W + 2 * pad - k) // stride + 1
+        out = self.buf(Ho, Wo, co)
+        wp = ops.pack_conv_weight(self.w(conv + ".weight"), stem=stem)
+        sc, sh = ops.fold_bn(co, self.bn(bn) if bn else None, self.w(conv + ".bias") if bias else None, self.dev)
+        srcs = [a.t for a in xs]
+        rt = res.t if res is not None else None
+        act = ops.ACT_RELU if relu else ops.ACT_NONE
+        ot = out.t
+        ci = sum(a.C for a in xs)
+
+        def fn():
+            ops.conv2d(srcs, wp, sc, sh, ot, kh=k, kw=k, stride=stride, pad=pad, cout=co, act=act, res=rt, in_nchw=stem)
+        self.add("conv", conv, 2 * Ho * Wo * co * ci * k * k, fn)
+        return out
+
+    def emit_maxpool(self, x, k, s, p):
+        key = (id(x), k, s, p)
+        if key in self._pool_cache:
+            return self._pool_cache[key]
+        out = self.buf((x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1, x.C)
+        xt, ot = x.t, out.t
+        self.add("pool", "maxpool%dx%d" % (k, k), 0, lambda: ops.maxpool2d(xt, ot, k, s, p))
+        self._pool_cache[key] = out
+        return out
+
+    def emit_dcn(self, x, name, co):
+        om = self.buf(x.H, x.W, 32)
+        wom = ops.pack_conv_weight(self.w(name + ".conv.conv_offset_mask.weight"))     # [9C, 32]
+        som, hom = ops.fold_bn(27, None, self.w(name + ".conv.conv_offset_mask.bias"), self.dev)
+        som[27:] = 0.0   # pad channels are written as exact zeros
+        out = self.buf(x.H, x.W, co)
+        wp = ops.pack_conv_weight(self.w(name + ".conv.weight"))
+        sc, sh = ops.fold_bn(co, self.bn(name + ".actf.0"), self.w(name + ".conv.bias"), self.dev)
+        xt, omt, ot = x.t, om.t, out.t
+
+        def fn_om():
+            ops.conv2d([xt], wom, som, hom, omt, kh=3, kw=3, stride=1, pad=1, cout=32)
+
+        def fn():
+            ops.dcn_v2(xt, omt, wp, sc, sh, ot, cout=co, om_sigmoid=True, act=ops.ACT_RELU)
+        self.add("conv", name + ".conv.conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9, fn_om)
+        self.add("dcn", name + ".conv", 2 * x.H * x.W * co * x.C * 9, fn)
+        return out
+
+    def emit_up_add(self, x, wname, f, add):
+        out = self.buf(x.H * f, x.W * f, x.C)
+        wk = ops.pack_dw_deconv_weight(self.w(wname + ".weight"))
+        xt, at, ot = x.t, add.t, out.t
+        self.add("up", wname, 2 * out.H * out.W * x.C * 4, lambda: ops.dw_deconv_add(xt, wk, at, ot, f))
+        return out
+
+    def emit_deconv4(self, x, wname, bn, co):
+        out = self.buf(x.H * 2, x.W * 2, co)
+        w = self.w(wname + ".weight")
+        sc, sh = ops.fold_bn(co, self.bn(bn), None, self.dev)
+        xt, ot, H, W = x.t, out.t, x.H, x.W
+        for py in range(2):
+            for px in range(2):
+                wp = ops.pack_deconv4_subpixel(w, py, px)
+
+                def fn(wp=wp, py=py, px=px):
+                    ops.conv2d([xt], wp, sc, sh, ot, kh=2, kw=2, stride=1, pad=0, pad_yx=(1 - py, 1 - px), cout=co,
+                               act=ops.ACT_RELU, Ho=H, Wo=W, out_scatter=(2, 2, py, px))
+                self.add("conv", "%s[%d%d]" % (wname, py, px), 2 * H * W * co * x.C * 4, fn)
+        return out
+
+    def emit_sum_up(self, xs, shifts, relu):
+        out = self.buf(xs[0].H, xs[0].W, xs[0].C)
+        ts, ot = [a.t for a in xs], out.t
+        self.add("sum", "fuse", 0, lambda: ops.sum_up(ts, shifts, ot, relu))
+        return out
+
+    def emit_head(self, feat, p, hc):
+        """six [3x3 conv + bias + ReLU] merged into one launch (Cout = 6*hc, shared A tile), then six
+        1x1 convs on channel slices writing the reference's NCHW outputs; hm / hm_hp get their
+        sigmoid (multi_pose.py:35-37) in the epilogue."""
+        H, W = feat.H, feat.W
+        mid = self.buf(H, W, 6 * hc)
+        w3 = torch.cat([self.w("%s.%s.0.weight" % (p, h)) for h, _ in nets.HEADS], 0)
+        b3 = torch.cat([self.w("%s.%s.0.bias" % (p, h)) for h, _ in nets.HEADS], 0)
+        wp3 = ops.pack_conv_weight(w3)
+        sc3, sh3 = ops.fold_bn(6 * hc, None, b3, self.dev)
+        ft, mt = feat.t, mid.t
+
+        def fn3():
+            ops.conv2d([ft], wp3, sc3, sh3, mt, kh=3, kw=3, stride=1, pad=1, cout=6 * hc, act=ops.ACT_RELU)
+        self.add("conv", p + ".*.0", 2 * H * W * 6 * hc * feat.C * 9, fn3)
+        outs = []
+        for i, (h, n) in enumerate(nets.HEADS):
+            o = torch.empty((self.B, n, H, W), dtype=torch.float32, device=self.dev)
+            wp = ops.pack_conv_weight(self.w("%s.%s.2.weight" % (p, h)))
+            sc, sh = ops.fold_bn(n, None, self.w("%s.%s.2.bias" % (p, h)), self.dev)
+            act = ops.ACT_SIGMOID if (self.sigmoid_heads and h in ("hm", "hm_hp")) else ops.ACT_NONE
+            sl = mt[..., i * hc:(i + 1) * hc]
+
+            def fn(sl=sl, wp=wp, sc=sc, sh=sh, o=o, n=n, act=act):
+                ops.conv2d([sl], wp, sc, sh, o, kh=1, kw=1, cout=n, act=act, out_nchw=True)
+            self.add("conv", "%s.%s.2" % (p, h), 2 * H * W * n * hc, fn)
+            outs.append(o)
+        self.outputs = outs
+        return outs
+
+
+class Engine:
+    """Static-shape inference engine for one (arch, batch, H, W)."""
+
+    def __init__(self, arch, state_dict, batch, height=512, width=512, device="cuda", head_conv=None,
+                 sigmoid_heads=True, use_graph=True):
+        if not torch.cuda.is_available():
+            raise _lib.CenterposeHipError("Engine needs a HIP device; there is no CPU fallback")
+        _lib.lib()
+        self.arch = nets.canonical_arch(arch)
+        self.B, self.H, self.W = batch, height, width
+        self.device = torch.device(device)
+        sd = normalize_state_dict(state_dict)
+        spec, _ = nets.param_spec(self.arch, height, width, head_conv)
+        missing = [k for k in spec if k not in sd and not k.endswith("num_batches_tracked")]
+        if missing:
+            raise KeyError("checkpoint is missing %d parameters, e.g. %s" % (len(missing), missing[:3]))
+        for k, shp in spec.items():
+            if k in sd and not k.endswith("num_batches_tracked") and tuple(sd[k].shape) != tuple(shp):
+                raise ValueError("parameter %s has shape %s, expected %s" % (k, tuple(sd[k].shape), shp))
+        with torch.cuda.device(self.device):
+            self.input = torch.zeros((batch, 3, height, width), dtype=torch.float32, device=self.device)
+            pb = PlanBuilder(sd, batch, self.device, sigmoid_heads)
+            pb.network(self.arch, Act(height, width, 3, self.input), head_conv)
+        self.launches = pb.launches
+        self.outputs = pb.outputs
+        self.flops_per_image = pb.flops
+        self.activation_bytes = pb.bytes_alloc
+        self.graph = None
+        self.use_graph = use_graph
+
+    # -- execution ------------------------------------------------------------------------------
+    def run_eager(self):
+        for _, _, _, fn in self.launches:
+            fn()
+
+    def capture(self):
+        """Capture the whole schedule into one hipGraph (launch-bound inner loop -> one replay)."""
+        s = torch.cuda.Stream(device=self.device)
+        s.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(s):
+            self.run_eager()     # warm-up: sets kernel attributes, loads code objects
+        torch.cuda.current_stream(self.device).wait_stream(s)
+        torch.cuda.synchronize(self.device)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run_eager()
+        self.graph = g
+
+    def forward(self, images):
+        """images: float32 NCHW [B,3,H,W] on the device -> [hm, wh, hps, reg, hm_hp, hp_offset] NCHW
+        (static output buffers, overwritten by the next call)."""
+        if tuple(images.shape) != tuple(self.input.shape):
+            raise ValueError("engine was planned for input %s, got %s" % (tuple(self.input.shape), tuple(images.shape)))
+        if images.data_ptr() != self.input.data_ptr():
+            self.input.copy_(images)
+        if self.use_graph:
+            if self.graph is None:
+                self.capture()
+            self.graph.replay()
+        else:
+            self.run_eager()
+        return self.outputs
+
+    __call__ = forward
+
+    def profile(self, iters=5):
+        """Per-launch timing with HIP events on the launch stream -> list of dicts."""
+        torch.cuda.synchronize(self.device)
+        self.run_eager()
+        recs = []
+        for kind, name, flops, fn in self.launches:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                fn()
+            e1.record()
+            e1.synchronize()
+            recs.append(dict(kind=kind, name=name, flops=flops, ms=e0.elapsed_time(e1) / iters))
+        return recs

@@ -1,0 +1,276 @@
+"""Network graphs of the hot path, written once and used three ways:
+
+* ``param_spec(arch)``     -- the reference checkpoint's key names / shapes (load-time validation,
+                              synthetic-weight generation);
+* ``Engine`` plan building -- the same walk emits the static schedule of fused HIP kernel launches
+                              (BN folded, weights repacked K-major, NHWC buffers pre-allocated);
+* FLOP accounting          -- algorithmic 2*MAC per launch for the roofline numbers.
+
+Structure follows the reference modules (they are *not* imported):
+  dla_34   lib/models/backbones/pose_dla_dcn.py   DLA :222-290, Tree :166-219, Root :145-163,
+           BasicBlock :29-57, DeformConv :336-348, IDAUp :351-377, DLAUp :381-404, DLASeg :437-447
+  res_50   lib/models/backbones/msra_resnet.py    Bottleneck :64-102, PoseResNet :113-208
+  hrnet    lib/models/backbones/pose_higher_hrnet.py :98-235, :245-503 + experiments/hrnet_w32_512.yaml:63-130
+  head     lib/models/heads/keypoint.py:14-42
+"""
+from collections import OrderedDict
+
+HEADS = (("hm", 1), ("wh", 2), ("hps", 34), ("reg", 2), ("hm_hp", 17), ("hp_offset", 2))
+# (INTERMEDIATE_CHANNEL, HEAD_CONV) per experiments/*.yaml
+ARCH_HEAD = {"dla_34": (64, 256), "res_50": (256, 64), "hrnet": (32, 64)}
+
+
+class Act:
+    """A feature map in the plan: NHWC, [B,H,W,C]; ``t`` is the device tensor (None in spec mode)."""
+    __slots__ = ("H", "W", "C", "t")
+
+    def __init__(self, H, W, C, t=None):
+        self.H, self.W, self.C, self.t = H, W, C, t
+
+
+class Graph:
+    """Walks a network.  Sub-classed by engine.PlanBuilder, which overrides the emit_* hooks."""
+
+    def __init__(self):
+        self.spec = OrderedDict()
+        self.flops = 0          # algorithmic 2*MAC per image actually scheduled
+
+    # ---- parameter registration -----------------------------------------------------------
+    def p_conv(self, name, co, ci, k, bias=False, kw=None):
+        self.spec[name + ".weight"] = (co, ci, k, kw or k)
+        if bias:
+            self.spec[name + ".bias"] = (co,)
+
+    def p_bn(self, name, c):
+        for s in ("weight", "bias", "running_mean", "running_var"):
+            self.spec["%s.%s" % (name, s)] = (c,)
+        self.spec[name + ".num_batches_tracked"] = ()
+
+    # ---- emit hooks (spec mode: shape propagation only) ---------------------------------------
+    def emit_conv(self, xs, conv, bn, bias, co, k, stride, pad, relu, res, stem):
+        x = xs[0]
+        return Act((x.H + 2 * pad - k) // stride + 1, (x.W + 2 * pad - k) // stride + 1, co)
+
+    def emit_maxpool(self, x, k, s, p):
+        return Act((x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1, x.C)
+
+    def emit_dcn(self, x, name, co):
+        return Act(x.H, x.W, co)
+
+    def emit_up_add(self, x, wname, f, add):
+        return Act(x.H * f, x.W * f, x.C)
+
+    def emit_deconv4(self, x, wname, bn, co):
+        return Act(x.H * 2, x.W * 2, co)
+
+    def emit_sum_up(self, xs, shifts, relu):
+        return Act(xs[0].H, xs[0].W, xs[0].C)
+
+    def emit_head(self, feat, p, hc):
+        return None
+
+    # ---- building blocks ------------------------------------------------------------------
+    def conv(self, xs, name, bn, co, k, stride=1, pad=0, relu=False, res=None, bias=False, stem=False):
+        xs = xs if isinstance(xs, (list, tuple)) else [xs]
+        ci = sum(x.C for x in xs)
+        self.p_conv(name, co, ci, k, bias)
+        if bn:
+            self.p_bn(bn, co)
+        out = self.emit_conv(xs, name, bn, bias, co, k, stride, pad, relu, res, stem)
+        self.flops += 2 * out.H * out.W * co * ci * k * k
+        return out
+
+    def deform(self, x, name, co):
+        """DeformConv = conv_offset_mask (3x3, 27 ch, bias) -> DCNv2 3x3 (bias) -> BN -> ReLU."""
+        self.p_bn(name + ".actf.0", co)
+        self.p_conv(name + ".conv", co, x.C, 3, True)
+        self.p_conv(name + ".conv.conv_offset_mask", 27, x.C, 3, True)
+        out = self.emit_dcn(x, name, co)
+        self.flops += 2 * x.H * x.W * x.C * 9 * (27 + co)
+        return out
+
+    def up_add(self, x, wname, f, add):
+        self.spec[wname + ".weight"] = (x.C, 1, 2 * f, 2 * f)
+        out = self.emit_up_add(x, wname, f, add)
+        self.flops += 2 * out.H * out.W * x.C * 4
+        return out
+
+    # ---- DLA-34 ------------------------------------------------------------------------------
+    def _dla_block(self, x, p, ci, co, stride, residual):
+        h = self.conv(x, p + ".conv1", p + ".bn1", co, 3, stride, 1, relu=True)
+        return self.conv(h, p + ".conv2", p + ".bn2", co, 3, 1, 1, relu=True, res=residual)
+
+    def _dla_tree(self, x, p, levels, ci, co, stride, level_root, root_dim=0, children=None, top=True):
+        children = [] if children is None else children
+        if root_dim == 0:
+            root_dim = 2 * co
+        if level_root:
+            root_dim += ci
+        bottom = self.emit_maxpool(x, stride, stride, 0) if stride > 1 else x
+        if ci != co:
+            # every Tree with in != out owns a `project`; only a levels==1 tree's output is consumed
+            # (Tree.forward passes `residual` to tree1, whose own forward overwrites it -- :206-219)
+            self.p_conv(p + ".project.0", co, ci, 1)
+            self.p_bn(p + ".project.1", co)
+        if level_root:
+            children.append(bottom)
+        if levels == 1:
+            residual = bottom
+            if ci != co:
+                residual = self.emit_conv([bottom], p + ".project.0", p + ".project.1", False, co, 1, 1, 0, False, None, False)
+                self.flops += 2 * residual.H * residual.W * co * ci
+            x1 = self._dla_block(x, p + ".tree1", ci, co, stride, residual)
+            x2 = self._dla_block(x1, p + ".tree2", co, co, 1, x1)
+            return self.conv([x2, x1] + children, p + ".root.conv", p + ".root.bn", co, 1, relu=True)
+        x1 = self._dla_tree(x, p + ".tree1", levels - 1, ci, co, stride, False)
+        children.append(x1)
+        return self._dla_tree(x1, p + ".tree2", levels - 1, co, co, 1, False, root_dim + co, children)
+
+    def dla34(self, x, p="backbone_model"):
+        ch, lv = [16, 32, 64, 128, 256, 512], [1, 1, 1, 2, 2, 1]
+        b = p + ".base"
+        y = []
+        x = self.conv(x, b + ".base_layer.0", b + ".base_layer.1", 16, 7, 1, 3, relu=True, stem=True)
+        x = self.conv(x, b + ".level0.0", b + ".level0.1", 16, 3, 1, 1, relu=True)
+        y.append(x)
+        x = self.conv(x, b + ".level1.0", b + ".level1.1", 32, 3, 2, 1, relu=True)
+        y.append(x)
+        for i in range(2, 6):
+            x = self._dla_tree(x, "%s.level%d" % (b, i), lv[i], ch[i - 1], ch[i], 2, i > 2)
+            y.append(x)
+        # DLAUp (startp = 2): ida_i works on layers[len-i-2 : len]
+        layers = list(y)
+        out = [layers[-1]]
+        for i in range(3):
+            o = ch[-i - 2]
+            self._ida_up("%s.dla_up.ida_%d" % (p, i), layers, len(layers) - i - 2, len(layers), o)
+            out.insert(0, layers[-1])
+        yy = [out[0], out[1], out[2]]          # reference clones; buffers here are never aliased
+        self._ida_up(p + ".ida_up", yy, 0, 3, 64, up_f=[1, 2, 4])
+        return yy[-1]
+
+    def _ida_up(self, p, layers, startp, endp, o, up_f=None):
+        for i in range(startp + 1, endp):
+            j = i - startp
+            f = 2 if up_f is None else up_f[j]
+            t = self.deform(layers[i], "%s.proj_%d" % (p, j), o)
+            u = self.up_add(t, "%s.up_%d" % (p, j), f, layers[i - 1])
+            layers[i] = self.deform(u, "%s.node_%d" % (p, j), o)
+
+    # ---- ResNet-50 ---------------------------------------------------------------------------
+    def res50(self, x, p="backbone_model"):
+        x = self.conv(x, p + ".conv1", p + ".bn1", 64, 7, 2, 3, relu=True, stem=True)
+        x = self.emit_maxpool(x, 3, 2, 1)
+        inpl = 64
+        for li, (planes, n, stride) in enumerate(zip([64, 128, 256, 512], [3, 4, 6, 3], [1, 2, 2, 2]), start=1):
+            for b in range(n):
+                q = "%s.layer%d.%d" % (p, li, b)
+                s = stride if b == 0 else 1
+                res = x
+                if b == 0:
+                    res = self.conv(x, q + ".downsample.0", q + ".downsample.1", planes * 4, 1, s, 0)
+                h = self.conv(x, q + ".conv1", q + ".bn1", planes, 1, relu=True)
+                h = self.conv(h, q + ".conv2", q + ".bn2", planes, 3, s, 1, relu=True)
+                x = self.conv(h, q + ".conv3", q + ".bn3", planes * 4, 1, relu=True, res=res)
+                inpl = planes * 4
+        for i in range(3):
+            wname, bn = "%s.deconv_layers.%d" % (p, 3 * i), "%s.deconv_layers.%d" % (p, 3 * i + 1)
+            self.spec[wname + ".weight"] = (inpl, 256, 4, 4)
+            self.p_bn(bn, 256)
+            x_in = x
+            x = self.emit_deconv4(x, wname, bn, 256)
+            self.flops += 2 * x_in.H * x_in.W * inpl * 256 * 16
+            inpl = 256
+        return x
+
+    # ---- HRNet-W32 ---------------------------------------------------------------------------
+    def _hr_basic(self, x, p):
+        h = self.conv(x, p + ".conv1", p + ".bn1", x.C, 3, 1, 1, relu=True)
+        return self.conv(h, p + ".conv2", p + ".bn2", x.C, 3, 1, 1, relu=True, res=x)
+
+    def _hr_module(self, xs, p, chans, multi_scale_output):
+        nb = len(chans)
+        xs = list(xs)
+        for i in range(nb):
+            for b in range(4):
+                xs[i] = self._hr_basic(xs[i], "%s.branches.%d.%d" % (p, i, b))
+        outs = []
+        for i in range(nb if multi_scale_output else 1):
+            terms, shifts = [], []
+            for j in range(nb):
+                if j == i:
+                    terms.append(xs[j]); shifts.append(0)
+                elif j > i:
+                    q = "%s.fuse_layers.%d.%d" % (p, i, j)
+                    terms.append(self.conv(xs[j], q + ".0", q + ".1", chans[i], 1)); shifts.append(j - i)
+                else:
+                    t = xs[j]
+                    for k in range(i - j):
+                        q = "%s.fuse_layers.%d.%d.%d" % (p, i, j, k)
+                        last = k == i - j - 1
+                        t = self.conv(t, q + ".0", q + ".1", chans[i] if last else chans[j], 3, 2, 1, relu=not last)
+                    terms.append(t); shifts.append(0)
+            outs.append(self.emit_sum_up(terms, shifts, True))
+        return outs
+
+    def hrnet_w32(self, x, p="backbone_model"):
+        x = self.conv(x, p + ".conv1", p + ".bn1", 64, 3, 2, 1, relu=True, stem=True)
+        x = self.conv(x, p + ".conv2", p + ".bn2", 64, 3, 2, 1, relu=True)
+        for b in range(4):
+            q = "%s.layer1.%d" % (p, b)
+            res = x if b else self.conv(x, q + ".downsample.0", q + ".downsample.1", 256, 1)
+            h = self.conv(x, q + ".conv1", q + ".bn1", 64, 1, relu=True)
+            h = self.conv(h, q + ".conv2", q + ".bn2", 64, 3, 1, 1, relu=True)
+            x = self.conv(h, q + ".conv3", q + ".bn3", 256, 1, relu=True, res=res)
+        pre, ys = [256], [x]
+        for si, (nmod, chans) in enumerate([(1, [32, 64]), (4, [32, 64, 128]), (3, [32, 64, 128, 256])], start=1):
+            xs = []
+            for i, c in enumerate(chans):
+                q = "%s.transition%d.%d" % (p, si, i)
+                if i < len(pre):
+                    xs.append(self.conv(ys[i], q + ".0", q + ".1", c, 3, 1, 1, relu=True) if c != pre[i] else ys[i])
+                else:
+                    t = ys[-1]
+                    for j in range(i + 1 - len(pre)):
+                        co = c if j == i - len(pre) else pre[-1]
+                        t = self.conv(t, "%s.%d.0" % (q, j), "%s.%d.1" % (q, j), co, 3, 2, 1, relu=True)
+                    xs.append(t)
+            for m in range(nmod):
+                last = (si == 3 and m == nmod - 1)
+                xs = self._hr_module(xs, "%s.stage%d.%d" % (p, si + 1, m), chans, not last)
+            ys, pre = xs, chans
+        return ys[0]
+
+    # ---- head --------------------------------------------------------------------------------
+    def head(self, feat, hc, p="head_model"):
+        for h, n in HEADS:
+            self.p_conv("%s.%s.0" % (p, h), hc, feat.C, 3, True)
+            self.p_conv("%s.%s.2" % (p, h), n, hc, 1, True)
+            self.flops += 2 * feat.H * feat.W * (hc * feat.C * 9 + n * hc)
+        return self.emit_head(feat, p, hc)
+
+    def network(self, arch, x, head_conv=None):
+        base = canonical_arch(arch)
+        inter, hc = ARCH_HEAD[base]
+        feat = {"dla_34": self.dla34, "res_50": self.res50, "hrnet": self.hrnet_w32}[base](x)
+        assert feat.C == inter
+        return self.head(feat, head_conv or hc)
+
+
+def canonical_arch(arch):
+    """cfg.MODEL.NAME -> graph name ('dla_34', 'res_50', 'hrnet'; model.py:49-52 parses 'x_N')."""
+    a = arch.lower()
+    if a in ("dla_34", "dla34"):
+        return "dla_34"
+    if a in ("res_50", "res50", "resnet_50"):
+        return "res_50"
+    if a.startswith("hrnet"):
+        return "hrnet"
+    raise ValueError("unsupported arch %r (the MI355X hot path covers dla_34, res_50, hrnet)" % arch)
+
+
+def param_spec(arch, H=512, W=512, head_conv=None):
+    """OrderedDict name -> shape of the reference checkpoint for `arch`, plus algorithmic FLOPs/image."""
+    g = Graph()
+    g.network(arch, Act(H, W, 3), head_conv)
+    return g.spec, g.flops
