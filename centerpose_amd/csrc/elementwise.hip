@@ -198,3 +198,36 @@ extern "C" int cp_fill_f32(float* p, float v, long long n, void* stream)
     CP_CHECK_LAUNCH("fill_kernel");
     return 0;
 }
+
+// ---- flip-test merge (multi_pose.py:45-53; models/utils.py:27-47), all on the device ------------
+// in[2,C,H,W] NCHW: image 0 and its mirrored twin.  out[1,C,H,W] = (in[0] + flip_w(in[1]') ) / 2 where
+// in[1]' optionally has channels permuted (left/right joint swap) and selected channels negated.
+// mode 0: plain W-flip (hm, wh).  mode 1: hm_hp: joint swap.  mode 2: hps: joint swap on (x,y) pairs,
+// x components negated (flip_lr_off).
+__global__ void flip_merge_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int H, int W, int mode,
+                                  const int* __restrict__ perm /* [J] joint permutation or NULL */)
+{
+    const long long total = (long long)C * H * W;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int c = (int)(i / ((long long)W * H));
+        int cs = c;
+        float sign = 1.f;
+        if (mode == 1) cs = perm[c];
+        else if (mode == 2) { cs = 2 * perm[c >> 1] + (c & 1); if ((c & 1) == 0) sign = -1.f; }
+        const float a = in[i];
+        const float b = in[total + ((long long)cs * H + y) * W + (W - 1 - x)] * sign;
+        out[i] = (a + b) / 2.0f;
+    }
+}
+
+extern "C" int cp_flip_merge_f32(const float* in, float* out, int C, int H, int W, int mode, const int* perm, void* stream)
+{
+    CP_CHECK_ARG(in && out && (mode == 0 || perm), "flip_merge: bad arguments");
+    const long long total = (long long)C * H * W;
+    hipLaunchKernelGGL(flip_merge_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, in, out, C, H, W, mode,
+                       perm);
+    CP_CHECK_LAUNCH("flip_merge_kernel");
+    return 0;
+}

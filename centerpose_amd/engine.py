@@ -28,7 +28,9 @@ class PlanBuilder(nets.Graph):
     def __init__(self, sd, B, device, sigmoid_heads=True):
         super().__init__()
         self.sd, self.B, self.dev = sd, B, device
-        self.sigmoid_heads = sigmoid_heads
+        if isinstance(sigmoid_heads, bool):
+            sigmoid_heads = ("hm", "hm_hp") if sigmoid_heads else ()
+        self.sigmoid_heads = tuple(sigmoid_heads)
         self.launches = []      # (kind, name, flops_per_batch, fn)
         self.bytes_alloc = 0
         self._pool_cache = {}
@@ -144,7 +146,7 @@ class PlanBuilder(nets.Graph):
             o = torch.empty((self.B, n, H, W), dtype=torch.float32, device=self.dev)
             wp = ops.pack_conv_weight(self.w("%s.%s.2.weight" % (p, h)))
             sc, sh = ops.fold_bn(n, None, self.w("%s.%s.2.bias" % (p, h)), self.dev)
-            act = ops.ACT_SIGMOID if (self.sigmoid_heads and h in ("hm", "hm_hp")) else ops.ACT_NONE
+            act = ops.ACT_SIGMOID if h in self.sigmoid_heads else ops.ACT_NONE
             sl = mt[..., i * hc:(i + 1) * hc]
 
             def fn(sl=sl, wp=wp, sc=sc, sh=sh, o=o, n=n, act=act):

@@ -1,0 +1,100 @@
+"""Model assembly and checkpoint I/O with the reference's names and behaviour
+(lib/models/model.py): ``create_model`` (:63-65), ``load_model`` (:67-120), ``save_model``
+(:122-131), ``BackBoneWithHead`` (:44-59).  The "module" is a holder of a reference-format
+state_dict plus a cache of compiled inference plans (engine.Engine) per input shape; forward runs
+the fused HIP schedule.  Weight loading / orchestration stays Python, compute does not."""
+import torch
+
+from . import engine, nets, synth
+
+
+class BackBoneWithHead:
+    def __init__(self, arch, head_conv, cfg):
+        self.arch = nets.canonical_arch(arch)                      # model.py:49-52 ('dla_34' -> dla, 34)
+        self.head_conv = head_conv
+        self.cfg = cfg
+        loss = cfg.LOSS if cfg is not None else None
+        self.sigmoid_hm_hp = bool(loss is None or (loss.HM_HP and not loss.MSE_LOSS))
+        # the reference starts from ImageNet weights it downloads (pose_dla_dcn.py:311-312,
+        # msra_resnet.py:227-230); offline we start from the seeded synthetic checkpoint instead
+        self._sd = synth.make_state_dict(self.arch, seed=getattr(cfg, "SEED", 317) if cfg is not None else 317,
+                                         head_conv=head_conv)
+        self.device = torch.device("cuda")
+        self._engines = {}
+        self.use_graph = True
+
+    # -- nn.Module-ish surface used by the detector --------------------------------------------
+    def state_dict(self):
+        return self._sd
+
+    def load_state_dict(self, sd, strict=False):
+        self._sd = {k: v.detach().cpu() for k, v in sd.items()}
+        self._engines.clear()
+
+    def to(self, device):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            from ._lib import CenterposeHipError
+            raise CenterposeHipError("centerpose_amd models run on the HIP device only")
+        self._engines.clear()
+        return self
+
+    def eval(self):
+        return self
+
+    def engine_for(self, B, H, W):
+        key = (B, H, W)
+        if key not in self._engines:
+            self._engines[key] = engine.Engine(self.arch, self._sd, B, H, W, device=self.device,
+                                               head_conv=self.head_conv, sigmoid_heads=("hm",) + (("hm_hp",) if self.sigmoid_hm_hp else ()),
+                                               use_graph=self.use_graph)
+        return self._engines[key]
+
+    def forward(self, x):
+        """x: float32 NCHW on the HIP device.  Returns the reference's list
+        [hm, wh, hps, reg, hm_hp, hp_offset] with hm (and hm_hp) ALREADY sigmoided -- the
+        in-place sigmoid of MultiPoseDetector.process (multi_pose.py:35-37) is fused into the
+        head epilogue."""
+        B, _, H, W = x.shape
+        return self.engine_for(B, H, W)(x)
+
+    __call__ = forward
+
+
+def create_model(arch, head_conv, cfg):
+    return BackBoneWithHead(arch, head_conv, cfg)
+
+
+def load_model(model, model_path, optimizer=None, resume=False, lr=None, lr_step=None):
+    """model.py:67-120 (inference subset): strips 'module.', keeps the model's tensor on a shape
+    mismatch, fills missing keys from the model, ignores unknown keys."""
+    checkpoint = torch.load(model_path, map_location=lambda storage, loc: storage)
+    print("loaded {}, epoch {}".format(model_path, checkpoint["epoch"]))
+    state_dict = engine.normalize_state_dict(checkpoint["state_dict"])
+    model_state_dict = model.state_dict()
+    msg = "If you see this, your model does not fully load the pre-trained weight."
+    for k in list(state_dict):
+        if k in model_state_dict:
+            if state_dict[k].shape != model_state_dict[k].shape:
+                print("Skip loading parameter {}, required shape{}, loaded shape{}. {}".format(
+                    k, model_state_dict[k].shape, state_dict[k].shape, msg))
+                state_dict[k] = model_state_dict[k]
+        else:
+            print("Drop parameter {}.".format(k) + msg)
+            del state_dict[k]
+    for k in model_state_dict:
+        if k not in state_dict:
+            print("No param {}.".format(k) + msg)
+            state_dict[k] = model_state_dict[k]
+    model.load_state_dict(state_dict, strict=False)
+    if optimizer is not None:
+        raise NotImplementedError("optimizer resume is training-only (out of scope for the inference hot path)")
+    return model
+
+
+def save_model(path, epoch, model, optimizer=None):
+    """model.py:122-131."""
+    data = {"epoch": epoch, "state_dict": model.state_dict()}
+    if optimizer is not None:
+        data["optimizer"] = optimizer.state_dict()
+    torch.save(data, path)

@@ -139,3 +139,43 @@ def multi_pose_decode(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100
         return dets, {"inds": inds, "hm_inds": hm_inds, "scores": scores,
                       "hm_score_topk": topk_channel(hm_hp, K)[0]}
     return dets
+
+
+# ---- flip-test merge (lib/detectors/multi_pose.py:45-53; lib/models/utils.py:27-47) ---------------
+FLIP_IDX = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]   # multi_pose.py:27
+
+
+def flip_tensor(x):
+    """utils.py:27-28"""
+    return x[..., ::-1].copy()
+
+
+def flip_lr(x, flip_idx=FLIP_IDX):
+    """utils.py:30-36"""
+    tmp = x[..., ::-1].copy()
+    for e in flip_idx:
+        tmp[:, e[0], ...], tmp[:, e[1], ...] = tmp[:, e[1], ...].copy(), tmp[:, e[0], ...].copy()
+    return tmp
+
+
+def flip_lr_off(x, flip_idx=FLIP_IDX):
+    """utils.py:38-47"""
+    tmp = x[..., ::-1].copy()
+    shape = tmp.shape
+    tmp = tmp.reshape(tmp.shape[0], 17, 2, tmp.shape[2], tmp.shape[3])
+    tmp[:, :, 0, :, :] *= -1
+    for e in flip_idx:
+        tmp[:, e[0], ...], tmp[:, e[1], ...] = tmp[:, e[1], ...].copy(), tmp[:, e[0], ...].copy()
+    return tmp.reshape(shape)
+
+
+def flip_merge(hm, wh, hps, reg, hm_hp, hp_offset):
+    """multi_pose.py:45-53 on a batch of exactly 2 (image, mirrored image)."""
+    two = F32(2)
+    hm = (hm[0:1] + flip_tensor(hm[1:2])) / two
+    wh = (wh[0:1] + flip_tensor(wh[1:2])) / two
+    hps = (hps[0:1] + flip_lr_off(hps[1:2])) / two
+    hm_hp = (hm_hp[0:1] + flip_lr(hm_hp[1:2])) / two if hm_hp is not None else None
+    reg = reg[0:1] if reg is not None else None
+    hp_offset = hp_offset[0:1] if hp_offset is not None else None
+    return hm, wh, hps, reg, hm_hp, hp_offset

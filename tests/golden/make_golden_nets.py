@@ -1,0 +1,68 @@
+"""Golden vectors for the network forward: the REFERENCE modules (imported from /root/reference in
+the build container) run on the seeded synthetic checkpoint; outputs are committed as data.
+The DCNv2 arithmetic inside dla_34 comes from oracle/dcn.py plugged in as the reference's `_ext`
+(the reference has no CPU DCN and cannot be built here) -- the graph, BN, convs, deconvs, head are
+the reference's own code."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/lib")
+warnings.filterwarnings("ignore")
+
+
+class AD(dict):
+    __getattr__ = dict.__getitem__
+
+
+def ad(d):
+    return AD({k: ad(v) if isinstance(v, dict) else v for k, v in d.items()})
+
+
+def build_reference(arch):
+    from oracle import dcn
+    sys.modules["_ext"] = dcn.ext_module()
+    from models.heads.keypoint import KeypointHead
+
+    class M(torch.nn.Module):
+        def __init__(s, b, h):
+            super().__init__()
+            s.backbone_model, s.head_model = b, h
+
+        def forward(s, x):
+            return s.head_model(s.backbone_model(x))
+    if arch == "dla_34":
+        from models.backbones.pose_dla_dcn import DLASeg
+        return M(DLASeg("dla34", False, 4, 1, 5), KeypointHead(64, 256)).eval()
+    if arch == "res_50":
+        from models.backbones.msra_resnet import PoseResNet, Bottleneck
+        return M(PoseResNet(Bottleneck, [3, 4, 6, 3]), KeypointHead(256, 64)).eval()
+    from models.backbones.pose_higher_hrnet import PoseHigherResolutionNet
+    cfg = ad(yaml.safe_load(open("/root/reference/experiments/hrnet_w32_512.yaml")))
+    return M(PoseHigherResolutionNet(cfg), KeypointHead(32, 64)).eval()
+
+
+def main(what=("nets",)):
+    from centerpose_amd import synth
+    for arch in ("dla_34", "res_50", "hrnet"):
+        m = build_reference(arch)
+        sd = synth.make_state_dict(arch)
+        assert set(sd) == set(m.state_dict()), (arch, set(sd) ^ set(m.state_dict()))
+        m.load_state_dict(sd, strict=True)
+        x = synth.make_images(1, 128, 128, seed=7)
+        with torch.no_grad():
+            outs = m(x)
+        np.savez_compressed(os.path.join(HERE, "net_%s_128.npz" % arch),
+                            **{"out%d" % i: o.numpy() for i, o in enumerate(outs)})
+        print("nets", arch, [tuple(o.shape) for o in outs][:2], "...")
+
+
+if __name__ == "__main__":
+    main()
