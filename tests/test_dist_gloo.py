@@ -1,0 +1,78 @@
+"""CPU, world_size 2 over gloo: the N>1 path of the hot path (contiguous batch sharding + one
+all-gather of the fixed-shape detections).  The per-rank compute is stood in for by the numpy decode
+oracle so the collective logic is what is under test."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, global_batch, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import cases
+    from centerpose_amd import dist as cpd
+    from oracle import decode_np
+    r, w, _ = cpd.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    inp = cases.decode_random(42, B=global_batch, H=32, W=32)
+    lo, hi = cpd.shard_range(global_batch, rank, world)
+    local = decode_np.multi_pose_decode(inp["hm"][lo:hi], inp["wh"][lo:hi], inp["hps"][lo:hi], inp["reg"][lo:hi],
+                                        inp["hm_hp"][lo:hi], inp["hp_offset"][lo:hi], K=20)
+    full = cpd.gather_dets(torch.from_numpy(local))
+    dist.barrier()
+    q.put((rank, full.numpy()))
+    dist.destroy_process_group()
+
+
+def _run(global_batch):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cases
+    from oracle import decode_np
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, global_batch, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    inp = cases.decode_random(42, B=global_batch, H=32, W=32)
+    ref = decode_np.multi_pose_decode(inp["hm"], inp["wh"], inp["hps"], inp["reg"], inp["hm_hp"], inp["hp_offset"], K=20)
+    for r in range(2):
+        assert res[r].shape == ref.shape and np.array_equal(res[r], ref)
+
+
+def test_allgather_equal_shards():
+    _run(4)
+
+
+def test_allgather_ragged_shards():
+    _run(5)
+
+
+def test_shard_range_covers_batch():
+    from centerpose_amd import dist as cpd
+    for gb in (1, 7, 16, 128):
+        for w in (1, 2, 4, 8):
+            spans = [cpd.shard_range(gb, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == gb
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
