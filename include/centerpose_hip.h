@@ -4,9 +4,11 @@
  * sizes, no torch types.  All pointers are DEVICE pointers unless stated; `stream` is a
  * hipStream_t (NULL = default stream).  Every function returns 0 on success, non-zero on error
  * (1 = bad argument, 2 = launch/runtime failure); cp_last_error() gives the message
- * (thread-local).  Nothing synchronises the host; nothing allocates device memory.
+ * (thread-local).  Nothing synchronises the host; nothing allocates device memory; kernels are
+ * enqueued on `stream` only (so a caller may capture a sequence of calls into a hipGraph).
  *
  * File:line citations are relative to the reference checkout (/root/reference).
+ * Activation layout: NHWC float32, `ld` = floats between consecutive pixels (>= C).
  */
 #ifndef CENTERPOSE_HIP_H
 #define CENTERPOSE_HIP_H
@@ -18,6 +20,73 @@ extern "C" {
 int cp_abi_version(void);
 const char* cp_target_arch(void);            /* "gfx950" */
 const char* cp_last_error(void);
+
+enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_SIGMOID = 2 };
+
+/* ---- fused convolution (implicit GEMM, fp32 MFMA) ------------------------------------------------
+ * Replaces nn.Conv2d + BatchNorm2d(eval) + ReLU + residual add + torch.cat (+ sigmoid) of
+ *   lib/models/backbones/pose_dla_dcn.py:29-57,145-163,272-282 (BasicBlock, Root, conv levels),
+ *   lib/models/backbones/msra_resnet.py:64-102,168-193 (Bottleneck, dense ConvTranspose2d k4 s2 p1 as
+ *   4 sub-pixel 2x2 convs via the osy/osx/ooy/oox output scatter),
+ *   lib/models/backbones/pose_higher_hrnet.py:98-235, lib/models/heads/keypoint.py:14-42,
+ *   and the in-place sigmoid of lib/detectors/multi_pose.py:35-37.
+ * out = act( (sum over up to 4 channel-concatenated sources of conv(src)) * scale + shift [+ res] ).
+ * w: packed weights [K][ldw], k = (ky*kw + kx)*Ctot + c  (inNCHW stem: k = (c*kh + ky)*kw + kx, K padded
+ * to a multiple of 16 with zero rows), ldw = Cout padded to 16 / 32 / a multiple of 64 with zero columns;
+ * scale/shift: [ldw] (folded BN or 1/bias).  res: NHWC residual with pixel stride resLd, or NULL. */
+typedef struct cp_conv_desc {
+    int nsrc;                 /* 1..4 sources */
+    int srcC[4], srcLd[4];    /* channels taken from / pixel stride of each source (C % 16 == 0 unless inNCHW) */
+    int B, H, W;              /* input spatial size */
+    int Ho, Wo;               /* output positions computed by this launch */
+    int kh, kw, sy, sx, py, px;
+    int K, ldw;
+    int Cout;                 /* channels stored */
+    int resLd, outLd;
+    int outNCHW;              /* 0: out is NHWC [B,OH,OW,outLd]; 1: out is NCHW [B,Cout,OH,OW] */
+    int OH, OW, osy, osx, ooy, oox;   /* output pixel = (oy*osy+ooy, ox*osx+oox) inside [OH,OW] */
+    int act;
+    int inNCHW;               /* 1: src[0] is the NCHW network input [B,srcC[0],H,W] (base_detector.py:53-58) */
+    int tile;                 /* 0 = auto; BM*1000+BN to force a kernel instantiation */
+} cp_conv_desc;
+int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale, const float* shift,
+                  const float* res, float* out, void* stream);
+
+/* ---- fused DCNv2 forward -------------------------------------------------------------------------
+ * Replaces dcn_v2_forward / dcn_v2_cuda_forward (DCNv2/src/dcn_v2.h:9-39, src/cuda/dcn_v2_cuda.cu:42-172,
+ * src/cuda/dcn_v2_im2col_cuda.cu:25-54,125-195) plus the BN + ReLU of DeformConv (pose_dla_dcn.py:345-348).
+ * x: NHWC [B,H,W,srcLd]; om: NHWC [B,Ho,Wo,omLd] with ch 2k = dy_k, 2k+1 = dx_k, 2*kh*kw + k = mask_k
+ * (logits if omSigmoid, as produced by conv_offset_mask, dcn_v2.py:117-121; already-sigmoided otherwise);
+ * w: [kh*kw*C][ldw]; deformable_group == 1 (the only value the reference uses). */
+typedef struct cp_dcn_desc {
+    int B, H, W, C, srcLd;
+    int Ho, Wo;
+    int kh, kw, sy, sx, py, px, dily, dilx;
+    int K, ldw, Cout;
+    int omLd, omSigmoid;
+    int outLd, outNCHW, act;
+    int tile;
+} cp_dcn_desc;
+int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* om, const float* w, const float* scale,
+                  const float* shift, float* out, void* stream);
+
+/* ---- bandwidth-bound NHWC helpers --------------------------------------------------------------- */
+/* nn.MaxPool2d (pose_dla_dcn.py:197-198 k2 s2; msra_resnet.py:123 k3 s2 p1) */
+int cp_maxpool2d_nhwc_f32(const float* in, int inLd, float* out, int outLd, int B, int H, int W, int C, int k, int s, int p,
+                          void* stream);
+/* IDAUp: depthwise ConvTranspose2d(k=2f, s=f, p=f/2, groups=C) + add (pose_dla_dcn.py:360-377); w: [k*k][C] */
+int cp_dw_deconv_add_nhwc_f32(const float* in, int inLd, const float* w, const float* add, int addLd, float* out, int outLd,
+                              int B, int H, int W, int C, int f, void* stream);
+/* HRNet fuse: out = relu?( sum_i nearest_upsample(src_i, 2^shift_i) ) (pose_higher_hrnet.py:217-235) */
+int cp_sum_up_nhwc_f32(int n, const float* const* src, const int* ld, const int* shift, float* out, int outLd, int B, int H,
+                       int W, int C, int relu, void* stream);
+int cp_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int outLd, int cOff, void* stream);
+int cp_nhwc_to_nchw_f32(const float* in, int inLd, int cOff, float* out, int B, int C, int H, int W, void* stream);
+int cp_fill_f32(float* p, float v, long long n, void* stream);
+/* flip-test merge (multi_pose.py:45-53; models/utils.py:27-47): in [2,C,H,W] NCHW -> out [1,C,H,W];
+ * mode 0 = W-flip average (hm, wh); 1 = + left/right joint swap (hm_hp); 2 = swap on (x,y) pairs + negate x (hps).
+ * perm: device int[J] joint permutation (NULL for mode 0). */
+int cp_flip_merge_f32(const float* in, float* out, int C, int H, int W, int mode, const int* perm, void* stream);
 
 /* ---- heat-map decode -------------------------------------------------------------------------
  * Replaces multi_pose_decode(heat, wh, kps, reg, hm_hp, hp_offset, K)
@@ -36,6 +105,11 @@ int cp_decode_workspace_bytes(int B, int J, int K, size_t* scores_bytes, size_t*
 int cp_multi_pose_decode_f32(const float* heat, const float* wh, const float* kps, const float* reg,
                              const float* hm_hp, const float* hp_offset, int B, int cat, int J, int H,
                              int W, int K, float* dets, float* ws_scores, int* ws_inds, void* stream);
+
+/* ---- host: soft-NMS of merged results --------------------------------------------------------
+ * Replaces soft_nms_39 (lib/external/nms.pyx:172-275; called from multi_pose.py:76-77).
+ * boxes: HOST float32 [N,56], modified in place with the reference's quirks; keep: HOST int[N] or NULL. */
+int cp_soft_nms_39(float* boxes, int N, float sigma, float Nt, float threshold, int method, int* keep, int* n_keep);
 
 #ifdef __cplusplus
 }

@@ -208,3 +208,26 @@ def test_dcn_zero_offset_identity():
     out = torch.empty(2, 10, 10, 32, device="cuda")
     ops.dcn_v2(_nhwc(x), om.cuda(), ops.pack_conv_weight(w.cuda()), sc, sh, out, cout=32, om_sigmoid=False)
     _close(2 * out.permute(0, 3, 1, 2), F.conv2d(x, w, None, 1, 1), 1e-5)
+
+
+@pytest.mark.parametrize("C,Co,k,s,p,d", [(8, 6, 3, 1, 1, 1), (16, 32, 3, 2, 1, 1), (32, 16, 3, 1, 2, 2), (5, 7, 1, 1, 0, 1)])
+def test_dcn_v2_forward_ext_dropin(C, Co, k, s, p, d):
+    """reference FFI signature (DCNv2/src/dcn_v2.h:9-23): NCHW in, new NCHW tensor out, any stride/pad/dilation."""
+    from centerpose_amd import dcn_v2_ext
+    from oracle import dcn as odcn
+    r = np.random.RandomState(C * 7 + k)
+    B, H, W = 2, 11, 9
+    Ho = (H + 2 * p - (d * (k - 1) + 1)) // s + 1
+    Wo = (W + 2 * p - (d * (k - 1) + 1)) // s + 1
+    x = r.randn(B, C, H, W).astype(np.float32)
+    w = (r.randn(Co, C, k, k) * 0.2).astype(np.float32)
+    b = r.randn(Co).astype(np.float32)
+    off = (r.randn(B, 2 * k * k, Ho, Wo) * 2).astype(np.float32)
+    m = r.rand(B, k * k, Ho, Wo).astype(np.float32)
+    ref = odcn.dcn_v2_forward_c(x, w, b, off, m, k, k, s, s, p, p, d, d, 1)
+    t = [torch.from_numpy(a).cuda() for a in (x, w, b, off, m)]
+    out = dcn_v2_ext.dcn_v2_forward(*t, k, k, s, s, p, p, d, d, 1)
+    assert out.shape == ref.shape and out.is_cuda
+    _close(out, torch.from_numpy(ref), 1e-4)
+    with pytest.raises(RuntimeError):
+        dcn_v2_ext.dcn_v2_forward(t[0].cpu(), *t[1:], k, k, s, s, p, p, d, d, 1)
