@@ -22,8 +22,8 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As0 = smem;
-    float* Bs0 = smem + 2 * IG_BK * T::LDA;
+    float* As0 = smem;                       // [2][BM][IG_LDK]
+    float* Bs0 = smem + 2 * T::A_FLOATS;     // [2][BN][IG_LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int NT = a.ldw / BN;
@@ -69,8 +69,10 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
             for (int s = 0; s < T::A_SLOTS; ++s) {
                 const int iy = ps[s].iy0 + ky, ix = ps[s].ix0 + kx;
                 const bool ok = ps[s].boff >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                ar[s] = ok ? *reinterpret_cast<const float4*>(sp + (size_t)(ps[s].boff + iy * a.W + ix) * ld + cl + q * 4)
-                           : make_float4(0.f, 0.f, 0.f, 0.f);
+                // branch-free: out-of-range taps read the (always valid) tensor base and are zeroed
+                const size_t off = ok ? (size_t)(ps[s].boff + iy * a.W + ix) * ld + cl + q * 4 : 0;
+                const float4 v = *reinterpret_cast<const float4*>(sp + off);
+                ar[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
         auto advance = [&]() {
@@ -81,26 +83,23 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
 #pragma unroll
             for (int s = 0; s < T::A_SLOTS; ++s) {
                 const int pl = (tid >> 2) + s * 64;
-                As[(q * 4 + 0) * T::LDA + pl] = ar[s].x;
-                As[(q * 4 + 1) * T::LDA + pl] = ar[s].y;
-                As[(q * 4 + 2) * T::LDA + pl] = ar[s].z;
-                As[(q * 4 + 3) * T::LDA + pl] = ar[s].w;
+                *reinterpret_cast<float4*>(As + pl * IG_LDK + q * 4) = ar[s];
             }
         };
 
         load_a(); advance();
-        ig_load_b<T, BN>(a, 0, n0, tid, br);
+        ig_load_b<T>(a, 0, n0, tid, br);
         store_a(As0);
-        ig_store_b<T, BN>(Bs0, tid, br);
+        ig_store_b<T>(Bs0, tid, br);
         __syncthreads();
         int cur = 0;
         for (int ks = 0; ks < nk; ++ks) {
             const bool more = ks + 1 < nk;
-            if (more) { load_a(); advance(); ig_load_b<T, BN>(a, (ks + 1) * IG_BK, n0, tid, br); }
-            ig_compute<T, MF>(As0 + cur * IG_BK * T::LDA, Bs0 + cur * IG_BK * T::LDB, wm0, wn0, lane, acc);
+            if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
+            ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc);
             if (more) {
-                store_a(As0 + (cur ^ 1) * IG_BK * T::LDA);
-                ig_store_b<T, BN>(Bs0 + (cur ^ 1) * IG_BK * T::LDB, tid, br);
+                store_a(As0 + (cur ^ 1) * T::A_FLOATS);
+                ig_store_b<T>(Bs0 + (cur ^ 1) * T::B_FLOATS, tid, br);
             }
             __syncthreads();
             cur ^= 1;
@@ -108,10 +107,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
     } else {
         // ---------------- stem producer: NCHW input, tiny C (3): k = (c*kh + ky)*kw + kx ------
         // thread -> one pixel column of the tile (consecutive lanes = consecutive x: coalesced),
-        // 16*BM/256 scalar gathers per k-step, written straight into As[k][m] (no transpose).
-        constexpr int EPT = IG_BK * BM / IG_THREADS;       // elements per thread per k-step
-        constexpr int KPT = EPT / (BM / 64 > 4 ? 4 : 1);   // (unused helper, kept simple below)
-        (void)KPT;
+        // 16*BM/256 scalar gathers per k-step, written straight into As[m][k].
         const float* sp = a.src[0];
         const int C = a.srcC[0], khw = a.kh * a.kw, Kreal = C * khw;
         // thread handles pixel pl = tid % BM and k rows kq, kq + (256/BM), ...
@@ -139,21 +135,21 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         };
         auto store_a = [&](float* As) {
 #pragma unroll
-            for (int e = 0; e < NPER; ++e) As[(kq + e * KSTRIDE) * T::LDA + pl] = ar[e];
+            for (int e = 0; e < NPER; ++e) As[pl * IG_LDK + kq + e * KSTRIDE] = ar[e];
         };
         load_a(0);
-        ig_load_b<T, BN>(a, 0, n0, tid, br);
+        ig_load_b<T>(a, 0, n0, tid, br);
         store_a(As0);
-        ig_store_b<T, BN>(Bs0, tid, br);
+        ig_store_b<T>(Bs0, tid, br);
         __syncthreads();
         int cur = 0;
         for (int ks = 0; ks < nk; ++ks) {
             const bool more = ks + 1 < nk;
-            if (more) { load_a((ks + 1) * IG_BK); ig_load_b<T, BN>(a, (ks + 1) * IG_BK, n0, tid, br); }
-            ig_compute<T, MF>(As0 + cur * IG_BK * T::LDA, Bs0 + cur * IG_BK * T::LDB, wm0, wn0, lane, acc);
+            if (more) { load_a((ks + 1) * IG_BK); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
+            ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc);
             if (more) {
-                store_a(As0 + (cur ^ 1) * IG_BK * T::LDA);
-                ig_store_b<T, BN>(Bs0 + (cur ^ 1) * IG_BK * T::LDB, tid, br);
+                store_a(As0 + (cur ^ 1) * T::A_FLOATS);
+                ig_store_b<T>(Bs0 + (cur ^ 1) * T::B_FLOATS, tid, br);
             }
             __syncthreads();
             cur ^= 1;
@@ -238,9 +234,10 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
         // heuristic: N tile from the padded channel count, M tile from how many blocks fill 256 CUs
         if (d->ldw % 64 != 0) tile = (d->ldw % 32 == 0) ? 128032 : 256016;
         else {
+            // measured on MI355X: 128x64 beats 128x128 (register pressure, occupancy 2) on every shape;
+            // 64x64 wins once a launch has fewer than ~3 blocks per CU
             const long long blocks128 = (long long)cp_cdiv(a.M, 128) * (d->ldw / 64);
-            if (d->ldw % 128 == 0 && (long long)cp_cdiv(a.M, 128) * (d->ldw / 128) >= 1024) tile = 128128;
-            else tile = blocks128 >= 768 ? 128064 : 64064;
+            tile = blocks128 >= 4096 ? 128064 : 64064;
         }
     }
     int rc = 0;

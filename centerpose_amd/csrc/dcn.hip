@@ -27,7 +27,7 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_igemm_kernel(const ConvArgs a)
     float4* s_w = reinterpret_cast<float4*>(smem);                 // [taps][BM] corner weights * mask
     int* s_code = reinterpret_cast<int*>(s_w + DCN_MAX_TAPS * BM); // [taps][BM] base | dx<<29 | dy<<30
     float* As0 = smem + DCN_MAX_TAPS * BM * 5;
-    float* Bs0 = As0 + 2 * IG_BK * T::LDA;
+    float* Bs0 = As0 + 2 * T::A_FLOATS;
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int NT = a.ldw / BN;
@@ -113,26 +113,28 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_igemm_kernel(const ConvArgs a)
         for (int s = 0; s < T::A_SLOTS; ++s) {
             const int pl = (tid >> 2) + s * 64;
             const float4 w = wq[s];
-            As[(q * 4 + 0) * T::LDA + pl] = w.x * c00[s].x + w.y * c01[s].x + w.z * c10[s].x + w.w * c11[s].x;
-            As[(q * 4 + 1) * T::LDA + pl] = w.x * c00[s].y + w.y * c01[s].y + w.z * c10[s].y + w.w * c11[s].y;
-            As[(q * 4 + 2) * T::LDA + pl] = w.x * c00[s].z + w.y * c01[s].z + w.z * c10[s].z + w.w * c11[s].z;
-            As[(q * 4 + 3) * T::LDA + pl] = w.x * c00[s].w + w.y * c01[s].w + w.z * c10[s].w + w.w * c11[s].w;
+            float4 v;
+            v.x = w.x * c00[s].x + w.y * c01[s].x + w.z * c10[s].x + w.w * c11[s].x;
+            v.y = w.x * c00[s].y + w.y * c01[s].y + w.z * c10[s].y + w.w * c11[s].y;
+            v.z = w.x * c00[s].z + w.y * c01[s].z + w.z * c10[s].z + w.w * c11[s].z;
+            v.w = w.x * c00[s].w + w.y * c01[s].w + w.z * c10[s].w + w.w * c11[s].w;
+            *reinterpret_cast<float4*>(As + pl * IG_LDK + q * 4) = v;
         }
     };
 
     load_a(); advance();
-    ig_load_b<T, BN>(a, 0, n0, tid, br);
+    ig_load_b<T>(a, 0, n0, tid, br);
     store_a(As0);
-    ig_store_b<T, BN>(Bs0, tid, br);
+    ig_store_b<T>(Bs0, tid, br);
     __syncthreads();
     int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
         const bool more = ks + 1 < nk;
-        if (more) { load_a(); advance(); ig_load_b<T, BN>(a, (ks + 1) * IG_BK, n0, tid, br); }
-        ig_compute<T, MF>(As0 + cur * IG_BK * T::LDA, Bs0 + cur * IG_BK * T::LDB, wm0, wn0, lane, acc);
+        if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
+        ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc);
         if (more) {
-            store_a(As0 + (cur ^ 1) * IG_BK * T::LDA);
-            ig_store_b<T, BN>(Bs0 + (cur ^ 1) * IG_BK * T::LDB, tid, br);
+            store_a(As0 + (cur ^ 1) * T::A_FLOATS);
+            ig_store_b<T>(Bs0 + (cur ^ 1) * T::B_FLOATS, tid, br);
         }
         __syncthreads();
         cur ^= 1;

@@ -1,15 +1,19 @@
 // Implicit-GEMM convolution core for gfx950, fp32 in / fp32 accumulate on the matrix cores
 // (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32: exact f32, 157 TFLOP/s dense peak).
 //
-// GEMM view:  out[m][n] = sum_k A[m][k] * Wp[k][n]
+// GEMM view:  out[m][n] = sum_k A[m][k] * W[n][k]
 //   m = (b, oy, ox) output pixel, n = output channel, k = (tap, input channel) with the input
 //   channel fastest (activations are NHWC, so a k-chunk of one pixel is contiguous in HBM).
 // Block tile BM x BN, k-step BK = 16, 256 threads = 4 wave64.  Per k-step:
-//   * A-producer (plain im2col gather, 3-channel NCHW stem gather, or DCNv2 bilinear sampler)
+//   * the A-producer (plain im2col gather, 3-channel NCHW stem gather, or DCNv2 bilinear sampler)
 //     loads its slice into registers while the previous slice is being multiplied,
-//   * the slice is written k-major into LDS (As[k][m], Bs[k][n]; row pads chosen so the
-//     transposing ds_write_b32 and the row-contiguous ds_read_b32 are both conflict-free),
-//   * every wave reads MFMA fragments with one ds_read_b32 per operand register.
+//   * both operands are staged K-CONTIGUOUS in LDS (As[m][k], Bs[n][k], row stride 20 floats):
+//     the global float4 goes to LDS with one ds_write_b128, no transpose;
+//   * fragments are read with ds_read_b128: lane (row i, k-group g) takes 4 consecutive k and
+//     feeds them to 4 successive MFMAs.  MFMA number s therefore multiplies the k-set
+//     {4g+s : g} -- a permutation of the k order that A and B share, so the sum is unchanged.
+//     One LDS instruction per operand per 4 MFMAs; the 20-float stride makes the 16-lane b128
+//     groups hit 64 distinct banks.
 // Two LDS buffers, one barrier per k-step.  Epilogue fuses scale/shift (folded BN or bias),
 // residual add, ReLU / sigmoid and writes NHWC (coalesced along n) or NCHW (transposed through
 // LDS so stores are coalesced along the pixel index).
@@ -17,6 +21,7 @@
 #include "common.h"
 
 #define IG_BK 16
+#define IG_LDK 20            // LDS row stride in floats (16 B aligned; conflict-free b128 reads)
 #define IG_THREADS 256
 #define IG_MAX_SRC 4
 
@@ -31,9 +36,9 @@ struct ConvArgs {
     int B, H, W;              // input spatial size
     int Ho, Wo, M;            // output positions computed by this launch; M = B*Ho*Wo
     int kh, kw, sy, sx, py, px;
-    int K;                    // kh*kw*Ctot rounded up to a multiple of 16 (zero weight rows)
-    const float* w;           // packed weights [K][ldw]
-    int ldw;
+    int K;                    // kh*kw*Ctot rounded up to a multiple of 16 (zero weight columns)
+    const float* w;           // packed weights [ldw][K]  (n-major, k contiguous)
+    int ldw;                  // Cout padded to the N tile (zero rows)
     const float* scale;       // [ldw]  y = acc*scale + shift
     const float* shift;
     const float* res;         // optional residual, NHWC
@@ -62,8 +67,8 @@ __device__ __forceinline__ int ig_xcd_remap(int id, int n)
 }
 
 template <int MF> struct IgAcc;
-template <> struct IgAcc<32> { typedef f32x16 type; static constexpr int N = 16; static constexpr int KS = 2; };
-template <> struct IgAcc<16> { typedef f32x4 type; static constexpr int N = 4; static constexpr int KS = 4; };
+template <> struct IgAcc<32> { typedef f32x16 type; static constexpr int N = 16; };
+template <> struct IgAcc<16> { typedef f32x4 type; static constexpr int N = 4; };
 
 template <int MF>
 __device__ __forceinline__ typename IgAcc<MF>::type ig_mfma(float a, float b, typename IgAcc<MF>::type c)
@@ -81,15 +86,13 @@ template <int MF> __device__ __forceinline__ int ig_row(int r, int lane)
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MF>
 struct IgTile {
-    static constexpr int LDA = BM + 2;           // LDA % 8 == 2: transposing b32 writes conflict-free
-    static constexpr int LDB = BN + 4;           // 16 B aligned rows for ds_write_b128
     static constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     static constexpr int TM = WM / MF, TN = WN / MF;
     static constexpr int A_SLOTS = BM * 4 / IG_THREADS;                  // float4 per thread per k-step
-    static constexpr int B_F4 = IG_BK * BN / 4;
+    static constexpr int B_F4 = BN * 4;                                  // float4 in one B slice
     static constexpr int B_SLOTS = (B_F4 + IG_THREADS - 1) / IG_THREADS;
-    static constexpr int A_BYTES = IG_BK * LDA * 4, B_BYTES = IG_BK * LDB * 4;
-    static constexpr int MAIN_BYTES = 2 * (A_BYTES + B_BYTES);
+    static constexpr int A_FLOATS = BM * IG_LDK, B_FLOATS = BN * IG_LDK;
+    static constexpr int MAIN_BYTES = 2 * (A_FLOATS + B_FLOATS) * 4;
     static constexpr int EPI_BYTES = BN * (BM + 1) * 4;                  // NCHW transposed epilogue
     static constexpr int SMEM = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
     static_assert(WAVES_M * WAVES_N * 64 == IG_THREADS, "4 waves");
@@ -97,29 +100,23 @@ struct IgTile {
     static_assert(A_SLOTS >= 1, "BM >= 64");
 };
 
-// ---- B (weights) tile: global -> regs -> LDS ---------------------------------------------
-template <class T, int BN>
+// ---- B (weights) slice: global [n][K] -> regs -> LDS Bs[n][k] --------------------------------
+template <class T>
 __device__ __forceinline__ void ig_load_b(const ConvArgs& a, int k0, int n0, int tid, float4 (&br)[T::B_SLOTS])
 {
 #pragma unroll
     for (int s = 0; s < T::B_SLOTS; ++s) {
         const int idx = tid + s * IG_THREADS;
-        if (idx < T::B_F4) {
-            const int kr = idx / (BN / 4), n4 = idx % (BN / 4);
-            br[s] = *reinterpret_cast<const float4*>(a.w + (size_t)(k0 + kr) * a.ldw + n0 + n4 * 4);
-        }
+        if (idx < T::B_F4) br[s] = *reinterpret_cast<const float4*>(a.w + (size_t)(n0 + (idx >> 2)) * a.K + k0 + (idx & 3) * 4);
     }
 }
-template <class T, int BN>
+template <class T>
 __device__ __forceinline__ void ig_store_b(float* Bs, int tid, const float4 (&br)[T::B_SLOTS])
 {
 #pragma unroll
     for (int s = 0; s < T::B_SLOTS; ++s) {
         const int idx = tid + s * IG_THREADS;
-        if (idx < T::B_F4) {
-            const int kr = idx / (BN / 4), n4 = idx % (BN / 4);
-            *reinterpret_cast<float4*>(Bs + kr * T::LDB + n4 * 4) = br[s];
-        }
+        if (idx < T::B_F4) *reinterpret_cast<float4*>(Bs + (idx >> 2) * IG_LDK + (idx & 3) * 4) = br[s];
     }
 }
 
@@ -128,21 +125,30 @@ template <class T, int MF>
 __device__ __forceinline__ void ig_compute(const float* As, const float* Bs, int wm0, int wn0, int lane,
                                            typename IgAcc<MF>::type (&acc)[T::TM][T::TN])
 {
-    constexpr int KS = IgAcc<MF>::KS;
-    const int kl = (MF == 32) ? (lane >> 5) : (lane >> 4);
-    const int il = lane & (MF - 1);
+    constexpr int G = 64 / MF;           // k-groups across the wave: 2 (32x32x2) or 4 (16x16x4)
+    constexpr int NH = IG_BK / (4 * G);  // b128 reads per operand row per k-step: 2 or 1
+    const int g = lane / MF, il = lane % MF;
+    float4 af[NH][T::TM], bf[NH][T::TN];
 #pragma unroll
-    for (int kk = 0; kk < IG_BK / KS; ++kk) {
-        float af[T::TM], bf[T::TN];
-        const int kr = kk * KS + kl;
+    for (int h = 0; h < NH; ++h) {
 #pragma unroll
-        for (int i = 0; i < T::TM; ++i) af[i] = As[kr * T::LDA + wm0 + i * MF + il];
+        for (int i = 0; i < T::TM; ++i)
+            af[h][i] = *reinterpret_cast<const float4*>(As + (wm0 + i * MF + il) * IG_LDK + h * 4 * G + g * 4);
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j) bf[j] = Bs[kr * T::LDB + wn0 + j * MF + il];
+        for (int j = 0; j < T::TN; ++j)
+            bf[h][j] = *reinterpret_cast<const float4*>(Bs + (wn0 + j * MF + il) * IG_LDK + h * 4 * G + g * 4);
+    }
+#pragma unroll
+    for (int h = 0; h < NH; ++h) {
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll
-            for (int j = 0; j < T::TN; ++j) acc[i][j] = ig_mfma<MF>(af[i], bf[j], acc[i][j]);
+            for (int j = 0; j < T::TN; ++j) {
+                acc[i][j] = ig_mfma<MF>(af[h][i].x, bf[h][j].x, acc[i][j]);
+                acc[i][j] = ig_mfma<MF>(af[h][i].y, bf[h][j].y, acc[i][j]);
+                acc[i][j] = ig_mfma<MF>(af[h][i].z, bf[h][j].z, acc[i][j]);
+                acc[i][j] = ig_mfma<MF>(af[h][i].w, bf[h][j].w, acc[i][j]);
+            }
     }
 }
 
@@ -161,27 +167,30 @@ __device__ __forceinline__ void ig_epilogue(const ConvArgs& a, float* smem, int 
     const int HoWo = a.Ho * a.Wo;
     const int cl = lane & (MF - 1);
     if (!a.outNCHW) {
+        const bool dense = (a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.OH == a.Ho && a.OW == a.Wo);
+        const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
 #pragma unroll
-        for (int j = 0; j < T::TN; ++j) {
-            const int n = n0 + wn0 + j * MF + cl;
-            const bool nok = n < a.Cout;
-            const float sc = a.scale[n], sh = a.shift[n];     // arrays are padded to ldw
+        for (int i = 0; i < T::TM; ++i) {
 #pragma unroll
-            for (int i = 0; i < T::TM; ++i) {
+            for (int r = 0; r < IgAcc<MF>::N; ++r) {
+                const int m = m0 + wm0 + i * MF + ig_row<MF>(r, lane);
+                if (m >= a.M) continue;
+                size_t opix = (size_t)m;
+                if (!dense) {
+                    const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
+                    opix = ((size_t)b * a.OH + (oy * a.osy + a.ooy)) * a.OW + (ox * a.osx + a.oox);
+                }
+                float* orow = a.out + opix * a.outLd;
+                const float* rrow = a.res ? a.res + opix * a.resLd : nullptr;
 #pragma unroll
-                for (int r = 0; r < IgAcc<MF>::N; ++r) {
-                    const int m = m0 + wm0 + i * MF + ig_row<MF>(r, lane);
-                    if (m < a.M && nok) {
-                        size_t opix;
-                        if (a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.OH == a.Ho && a.OW == a.Wo) {
-                            opix = (size_t)m;
-                        } else {
-                            const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
-                            opix = ((size_t)b * a.OH + (oy * a.osy + a.ooy)) * a.OW + (ox * a.osx + a.oox);
-                        }
-                        float v = acc[i][j][r] * sc + sh;
-                        if (a.res) v += a.res[opix * a.resLd + n];
-                        a.out[opix * a.outLd + n] = ig_act(v, a.act);
+                for (int j = 0; j < T::TN; ++j) {
+                    const int n = n0 + wn0 + j * MF + cl;
+                    if (n < a.Cout) {
+                        float v = acc[i][j][r] * a.scale[n] + a.shift[n];
+                        if (rrow) v += rrow[n];
+                        if (relu) v = fmaxf(v, 0.f);
+                        else if (sigm) v = 1.0f / (1.0f + __expf(-v));
+                        orow[n] = v;
                     }
                 }
             }

@@ -31,13 +31,13 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
-def pad_cols(t, ldw):
-    """[K, Co] -> [K, ldw] zero padded, contiguous."""
-    K, Co = t.shape
+def pad_rows(t, ldw):
+    """[Co, K] -> [ldw, K] zero padded, contiguous (n-major packed weights)."""
+    Co, K = t.shape
     if Co == ldw:
         return t.contiguous()
-    out = torch.zeros((K, ldw), dtype=t.dtype, device=t.device)
-    out[:, :Co] = t
+    out = torch.zeros((ldw, K), dtype=t.dtype, device=t.device)
+    out[:Co] = t
     return out
 
 
@@ -57,17 +57,17 @@ def ldw_for(cout):
 
 
 def pack_conv_weight(w, stem=False):
-    """torch conv weight [Co,Ci,kh,kw] -> K-major [K, ldw].
+    """torch conv weight [Co,Ci,kh,kw] -> packed [ldw, K] (n-major, k contiguous).
     NHWC producer: k = (ky*kw + kx)*Ci + c.   Stem (NCHW input): k = (c*kh + ky)*kw + kx, K padded to 16."""
     Co, Ci, kh, kw = w.shape
     if stem:
-        wp = w.reshape(Co, Ci * kh * kw).t()
+        wp = w.reshape(Co, Ci * kh * kw)
         K = round_up(Ci * kh * kw, 16)
-        if K != wp.shape[0]:
-            wp = torch.cat([wp, torch.zeros((K - wp.shape[0], Co), dtype=w.dtype, device=w.device)], 0)
+        if K != wp.shape[1]:
+            wp = torch.cat([wp, torch.zeros((Co, K - wp.shape[1]), dtype=w.dtype, device=w.device)], 1)
     else:
-        wp = w.permute(2, 3, 1, 0).reshape(kh * kw * Ci, Co)
-    return pad_cols(wp.float(), ldw_for(Co))
+        wp = w.permute(0, 2, 3, 1).reshape(Co, kh * kw * Ci)
+    return pad_rows(wp.float(), ldw_for(Co))
 
 
 def fold_bn(cout, bn=None, bias=None, device=None):
@@ -118,7 +118,7 @@ def conv2d(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=AC
         Wo = (W + 2 * px - kw) // stride + 1
     d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
     d.kh, d.kw, d.sy, d.sx, d.py, d.px = kh, kw, stride, stride, py, px
-    d.K, d.ldw, d.Cout = wp.shape[0], wp.shape[1], cout
+    d.K, d.ldw, d.Cout = wp.shape[1], wp.shape[0], cout
     d.resLd = _ld(res) if res is not None else 0
     d.outNCHW = 1 if out_nchw else 0
     if out_nchw:
@@ -146,7 +146,7 @@ def dcn_v2(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, pad=1, d
     assert om.shape[:3] == (B, Ho, Wo)
     d.B, d.H, d.W, d.C, d.srcLd, d.Ho, d.Wo = B, H, W, C, _ld(x), Ho, Wo
     d.kh, d.kw, d.sy, d.sx, d.py, d.px, d.dily, d.dilx = kh, kw, stride, stride, pad, pad, dil, dil
-    d.K, d.ldw, d.Cout = wp.shape[0], wp.shape[1], cout
+    d.K, d.ldw, d.Cout = wp.shape[1], wp.shape[0], cout
     d.omLd, d.omSigmoid = _ld(om), 1 if om_sigmoid else 0
     d.outNCHW = 1 if out_nchw else 0
     d.outLd = 0 if out_nchw else _ld(out)
@@ -222,5 +222,5 @@ def pack_deconv4_subpixel(w, py, px):
     kys = [3 - py - 2 * t for t in range(2)]
     kxs = [3 - px - 2 * t for t in range(2)]
     sub = w[:, :, kys][:, :, :, kxs]                      # [Ci,Co,2,2] indexed by (ty,tx)
-    wp = sub.permute(2, 3, 0, 1).reshape(4 * Ci, Co)      # k = (ty*2+tx)*Ci + c
-    return pad_cols(wp.float().contiguous(), ldw_for(Co))
+    wp = sub.permute(1, 2, 3, 0).reshape(Co, 4 * Ci)      # k = (ty*2+tx)*Ci + c
+    return pad_rows(wp.float().contiguous(), ldw_for(Co))
