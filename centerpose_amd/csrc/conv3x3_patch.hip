@@ -1,0 +1,205 @@
+// 3x3 / stride 1 / pad 1 convolution with an LDS-resident input patch (gfx950, fp32 MFMA).
+//
+// The generic implicit-GEMM kernel (conv_igemm.hip) re-gathers every input pixel once per tap:
+// 9x the global loads, 9x the LDS writes and one barrier per 16-deep k-step.  3x3/s1 layers are
+// ~75 % of the network's FLOPs (DLA base blocks, DCN offset convs, the six head convs), so this
+// kernel stages, per 16-channel chunk, the (8+2) x (16+2) pixel halo patch of an 8x16 output
+// tile ONCE and lets all nine taps read their MFMA A-fragments straight out of it:
+//   A fragment of output pixel (y,x), tap (ky,kx)  =  patch[(y+ky)][(x+kx)][16 ch]   (one ds_read_b128)
+// Patch rows are padded to 384 floats so that the two pixel rows a 32-row MFMA tile spans fall on
+// the same bank pattern (384 = 0 mod 64) and the 20-float pixel stride keeps b128 reads
+// conflict-free.  The chunk's weights for all nine taps sit next to it (Bs[9][BN][20]).
+// Per chunk and wave: 54 ds_read_b128, 144 MFMAs (TM=2,TN=1), two barriers -- versus 9 barriers,
+// 9x the staging traffic before.  Global loads for chunk c+1 are in flight during chunk c.
+#include "igemm.h"
+
+#define P3_TH 8
+#define P3_TW 16
+#define P3_PH (P3_TH + 2)
+#define P3_PW (P3_TW + 2)
+#define P3_PITCH 384                       // floats per patch row (18*20 = 360, padded: = 0 mod 64)
+#define P3_PATCH (P3_PH * P3_PITCH)        // floats per patch buffer
+#define P3_PIX4 (P3_PH * P3_PW * 4)        // float4 per patch chunk (720)
+#define P3_ASLOTS ((P3_PIX4 + IG_THREADS - 1) / IG_THREADS)
+
+template <int BN, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(   // LDS admits 2 blocks/CU: allow 256 VGPRs
+const ConvArgs a, int tilesX, int tilesY)
+{
+    constexpr int MF = 32;
+    constexpr int WROWS = P3_TH / WAVES_M;            // output rows per wave (4 or 2)
+    constexpr int TM = WROWS / 2;                     // one 32-row MFMA tile = 2 rows x 16 cols
+    constexpr int WN = BN / WAVES_N, TN = WN / MF;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch0 = smem;                             // [P3_PATCH]
+    float* Bs = smem + P3_PATCH;                      // [9][BN][IG_LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int NT = a.ldw / BN;
+    const int tile = ig_xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = tile % NT;
+    int sp_ = tile / NT;
+    const int tx = sp_ % tilesX; sp_ /= tilesX;
+    const int ty = sp_ % tilesY;
+    const int b = sp_ / tilesY;
+    const int y0 = ty * P3_TH, x0 = tx * P3_TW, n0 = nt * BN;
+    const int wy0 = (wid / WAVES_N) * WROWS, wn0 = (wid % WAVES_N) * WN;
+    const int C = a.srcC[0], ld = a.srcLd[0];
+    const float* __restrict__ x = a.src[0];
+    const int g = lane >> 5, il = lane & 31;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- staging assignments (fixed per thread) ----
+    // (element offsets fit 32 bits: checked on the host)
+    int a_goff0, a_goff1, a_goff2, a_lds0, a_lds1, a_lds2;
+    {
+        int go[P3_ASLOTS], lo[P3_ASLOTS];
+#pragma unroll
+        for (int s = 0; s < P3_ASLOTS; ++s) {
+            const int idx = tid + s * IG_THREADS;
+            const int pp = idx >> 2, q = idx & 3;
+            const int pr = pp / P3_PW, pc = pp - pr * P3_PW;
+            const int yy = y0 - 1 + pr, xx = x0 - 1 + pc;
+            const bool ok = idx < P3_PIX4 && yy >= 0 && yy < a.H && xx >= 0 && xx < a.W;
+            go[s] = ok ? ((b * a.H + yy) * a.W + xx) * ld + q * 4 : -1;
+            lo[s] = idx < P3_PIX4 ? pr * P3_PITCH + pc * IG_LDK + q * 4 : -1;
+        }
+        a_goff0 = go[0]; a_goff1 = go[1]; a_goff2 = go[2];
+        a_lds0 = lo[0]; a_lds1 = lo[1]; a_lds2 = lo[2];
+    }
+    static_assert(P3_ASLOTS == 3, "three patch slots per thread");
+    // weight staging: thread -> fixed (n, q); slot s covers tap s (BN=64) or taps 2s + (tid>>7) (BN=32)
+    constexpr int TPS = IG_THREADS / (BN * 4);        // taps covered by one slot: 1 or 2
+    const int b_n = (tid >> 2) % BN, b_q = tid & 3, b_t0 = tid / (BN * 4);
+    const float* wrow = a.w + (size_t)(n0 + b_n) * a.K + b_q * 4;
+    float* bdst = Bs + (b_t0 * BN + b_n) * IG_LDK + b_q * 4;
+    float4 ar0, ar1, ar2, b0, b1, b2, b3, b4, b5, b6, b7, b8;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define P3_LB(s, c0) ((TPS * (s) + b_t0 < 9) ? *reinterpret_cast<const float4*>(wrow + (TPS * (s) + b_t0) * C + (c0)) : zero4)
+#define P3_SB(s, v) if (TPS * (s) + b_t0 < 9) *reinterpret_cast<float4*>(bdst + TPS * (s) * BN * IG_LDK) = (v)
+#define P3_LOAD(c0)                                                                                          \
+    {                                                                                                        \
+        const float4 v0 = *reinterpret_cast<const float4*>(x + (a_goff0 >= 0 ? a_goff0 + (c0) : 0));        \
+        const float4 v1 = *reinterpret_cast<const float4*>(x + (a_goff1 >= 0 ? a_goff1 + (c0) : 0));        \
+        const float4 v2 = *reinterpret_cast<const float4*>(x + (a_goff2 >= 0 ? a_goff2 + (c0) : 0));        \
+        ar0 = a_goff0 >= 0 ? v0 : zero4;                                                                     \
+        ar1 = a_goff1 >= 0 ? v1 : zero4;                                                                     \
+        ar2 = a_goff2 >= 0 ? v2 : zero4;                                                                     \
+        b0 = P3_LB(0, c0); b1 = P3_LB(1, c0); b2 = P3_LB(2, c0); b3 = P3_LB(3, c0); b4 = P3_LB(4, c0);       \
+        if (TPS == 1) { b5 = P3_LB(5, c0); b6 = P3_LB(6, c0); b7 = P3_LB(7, c0); b8 = P3_LB(8, c0); }        \
+    }
+#define P3_STORE(patch)                                                                                      \
+    {                                                                                                        \
+        if (a_lds0 >= 0) *reinterpret_cast<float4*>((patch) + a_lds0) = ar0;                                \
+        if (a_lds1 >= 0) *reinterpret_cast<float4*>((patch) + a_lds1) = ar1;                                \
+        if (a_lds2 >= 0) *reinterpret_cast<float4*>((patch) + a_lds2) = ar2;                                \
+        P3_SB(0, b0); P3_SB(1, b1); P3_SB(2, b2); P3_SB(3, b3); P3_SB(4, b4);                                \
+        if (TPS == 1) { P3_SB(5, b5); P3_SB(6, b6); P3_SB(7, b7); P3_SB(8, b8); }                            \
+    }
+
+    // lane's fragment bases: A row il -> pixel (il>>4, il&15) of MFMA tile i; B row il -> channel
+    const int a_lane = (wy0 + (il >> 4)) * P3_PITCH + (il & 15) * IG_LDK + g * 4;
+    const int b_lane = (wn0 + il) * IG_LDK + g * 4;
+
+    const int nchunk = C / IG_BK;
+    P3_LOAD(0);
+    P3_STORE(patch0);
+    __syncthreads();
+    const float* P = patch0 + a_lane;
+    const float* Q = Bs + b_lane;
+    for (int ci = 0; ci < nchunk; ++ci) {
+        const bool more = ci + 1 < nchunk;
+        if (more) P3_LOAD((ci + 1) * IG_BK);
+        // fragments double-buffered in registers: tap t+1 is read from LDS while tap t multiplies
+        float4 af[2][2][TM], bf[2][2][TN];
+#define P3_FRAG(buf, t)                                                                                      \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                      \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
+                af[buf][h][i] = *reinterpret_cast<const float4*>(P + (i * 2 + (t) / 3) * P3_PITCH + ((t) % 3) * IG_LDK + h * 8); \
+            _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
+                bf[buf][h][j] = *reinterpret_cast<const float4*>(Q + ((t) * BN + j * MF) * IG_LDK + h * 8);  \
+        }
+        P3_FRAG(0, 0)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int cb = t & 1;
+            if (t + 1 < 9) { P3_FRAG(cb ^ 1, t + 1) }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][h][i].x, bf[cb][h][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][h][i].y, bf[cb][h][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][h][i].z, bf[cb][h][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][h][i].w, bf[cb][h][j].w, acc[i][j], 0, 0, 0);
+                    }
+        }
+        __syncthreads();                // all waves are done with Bs and the patch
+        if (more) P3_STORE(patch0);
+        __syncthreads();
+    }
+
+    // ---- epilogue: scale/shift (+residual) + activation, NHWC stores coalesced along n ----
+    const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int rowl = ig_row<32>(r, lane);
+            const int yy = y0 + wy0 + i * 2 + (rowl >> 4), xx = x0 + (rowl & 15);
+            if (yy >= a.H || xx >= a.W) continue;
+            const size_t opix = ((size_t)b * a.H + yy) * a.W + xx;
+            float* orow = a.out + opix * a.outLd;
+            const float* rrow = a.res ? a.res + opix * a.resLd : nullptr;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn0 + j * MF + il;
+                if (n < a.Cout) {
+                    float v = acc[i][j][r] * a.scale[n] + a.shift[n];
+                    if (rrow) v += rrow[n];
+                    if (relu) v = fmaxf(v, 0.f);
+                    else if (sigm) v = 1.0f / (1.0f + __expf(-v));
+                    orow[n] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BN, int WAVES_M, int WAVES_N>
+static int launch_patch(const ConvArgs& a, hipStream_t s)
+{
+    auto kern = conv3x3_patch_kernel<BN, WAVES_M, WAVES_N>;
+    const int smem = (P3_PATCH + 9 * BN * IG_LDK) * 4;
+    static bool attr = false;
+    if (!attr && smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) { cp_set_error("conv3x3_patch: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
+        attr = true;
+    }
+    const int tilesX = cp_cdiv(a.W, P3_TW), tilesY = cp_cdiv(a.H, P3_TH);
+    const long long grid = (long long)a.B * tilesX * tilesY * (a.ldw / BN);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, tilesX, tilesY);
+    return 0;
+}
+
+// eligibility + dispatch; returns -1 if the shape is not handled here (caller falls back to the generic kernel)
+int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s)
+{
+    const bool ok = !in_nchw && a.nsrc == 1 && a.kh == 3 && a.kw == 3 && a.sy == 1 && a.sx == 1 && a.py == 1 && a.px == 1 &&
+                    !a.outNCHW && a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Ho == a.H && a.Wo == a.W &&
+                    a.OH == a.H && a.OW == a.W && a.srcC[0] % 16 == 0 && (a.ldw % 64 == 0 || a.ldw == 32);
+    if (!ok) return -1;
+    if (a.ldw == 32) return launch_patch<32, 4, 1>(a, s);
+    return launch_patch<64, 2, 2>(a, s);
+}

@@ -62,7 +62,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         // k-walk state (wave-uniform): tap (ky,kx), source index, channel offset inside the source
         int ky = 0, kx = 0, si = 0, cl = 0;
 
-        auto load_a = [&]() {
+        auto load_a = [&]() __attribute__((always_inline)) {
             const float* sp = a.src[si];
             const int ld = a.srcLd[si];
 #pragma unroll
@@ -75,11 +75,11 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
                 ar[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
-        auto advance = [&]() {
+        auto advance = [&]() __attribute__((always_inline)) {
             cl += IG_BK;
             if (cl >= a.srcC[si]) { cl = 0; if (++si >= a.nsrc) { si = 0; if (++kx >= a.kw) { kx = 0; ++ky; } } }
         };
-        auto store_a = [&](float* As) {
+        auto store_a = [&](float* As) __attribute__((always_inline)) {
 #pragma unroll
             for (int s = 0; s < T::A_SLOTS; ++s) {
                 const int pl = (tid >> 2) + s * 64;
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
             ix0 = ox * a.sx - a.px;
         }
         float ar[NPER];
-        auto load_a = [&](int k0) {
+        auto load_a = [&](int k0) __attribute__((always_inline)) {
 #pragma unroll
             for (int e = 0; e < NPER; ++e) {
                 const int k = k0 + kq + e * KSTRIDE;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
                 ar[e] = ok ? sp[(size_t)boff + ((size_t)c * a.H + iy) * a.W + ix] : 0.f;
             }
         };
-        auto store_a = [&](float* As) {
+        auto store_a = [&](float* As) __attribute__((always_inline)) {
 #pragma unroll
             for (int e = 0; e < NPER; ++e) As[pl * IG_LDK + kq + e * KSTRIDE] = ar[e];
         };
@@ -230,6 +230,15 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
     hipStream_t s = (hipStream_t)stream;
 
     int tile = d->tile;
+    if (tile == 0 || tile == 3) {   // 3x3/s1/p1 NHWC: LDS-resident halo patch kernel (conv3x3_patch.hip)
+        const int prc = cp_launch_conv3x3_patch(a, d->inNCHW, s);
+        if (prc >= 0) {
+            if (prc) return prc;
+            CP_CHECK_LAUNCH("conv3x3_patch_kernel");
+            return 0;
+        }
+        CP_CHECK_ARG(tile == 0, "conv2d: tile=3 (patch kernel) requested for an ineligible shape");
+    }
     if (tile == 0) {
         // heuristic: N tile from the padded channel count, M tile from how many blocks fill 256 CUs
         if (d->ldw % 64 != 0) tile = (d->ldw % 32 == 0) ? 128032 : 256016;

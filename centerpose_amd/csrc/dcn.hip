@@ -93,7 +93,7 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_igemm_kernel(const ConvArgs a)
     int tap = 0, cl = 0;
     __syncthreads();
 
-    auto load_a = [&]() {
+    auto load_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < T::A_SLOTS; ++s) {
             const int pl = (tid >> 2) + s * 64;
@@ -107,8 +107,8 @@ __global__ __launch_bounds__(IG_THREADS) void dcn_igemm_kernel(const ConvArgs a)
             c11[s] = *reinterpret_cast<const float4*>(p0 + (size_t)dy * a.W * ld + dx * ld);
         }
     };
-    auto advance = [&]() { cl += IG_BK; if (cl >= C) { cl = 0; ++tap; } };
-    auto store_a = [&](float* As) {
+    auto advance = [&]() __attribute__((always_inline)) { cl += IG_BK; if (cl >= C) { cl = 0; ++tap; } };
+    auto store_a = [&](float* As) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < T::A_SLOTS; ++s) {
             const int pl = (tid >> 2) + s * 64;

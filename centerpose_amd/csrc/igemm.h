@@ -58,6 +58,9 @@ struct ConvArgs {
     int dily, dilx;           // dilation (DCNv2 drop-in only; plain convs are dilation 1)
 };
 
+// conv3x3_patch.hip: returns -1 when the shape is not eligible, else 0 / error code
+int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s);
+
 // XCD-aware, bijective remap of the linear block id: blocks that are consecutive in the
 // remapped order (and share the same activation rows) land on the same XCD / L2.
 __device__ __forceinline__ int ig_xcd_remap(int id, int n)

@@ -46,12 +46,15 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
     om = torch.zeros((B, Ho, Wo, omld), dtype=torch.float32, device=input.device)
     ops.nchw_to_nhwc(offset.contiguous(), om, 0)
     ops.nchw_to_nhwc(mask.contiguous(), om, 2 * kk)
-    wpad = weight
-    if Cp != C:
-        wpad = torch.zeros((Co, Cp, kernel_h, kernel_w), dtype=torch.float32, device=input.device)
-        wpad[:, :C] = weight
+    Cop = max(Co, 17)                    # the DCN kernel's smallest N tile is 32: pad tiny Co with zero rows
+    wpad, bpad = weight, bias
+    if Cp != C or Cop != Co:
+        wpad = torch.zeros((Cop, Cp, kernel_h, kernel_w), dtype=torch.float32, device=input.device)
+        wpad[:Co, :C] = weight
+        bpad = torch.zeros(Cop, dtype=torch.float32, device=input.device)
+        bpad[:Co] = bias
     wp = ops.pack_conv_weight(wpad)
-    sc, sh = ops.fold_bn(Co, None, bias, input.device)
+    sc, sh = ops.fold_bn(Cop, None, bpad, input.device)
     out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=input.device)
     ops.dcn_v2(x, om, wp, sc, sh, out, cout=Co, kh=kernel_h, kw=kernel_w, stride=stride_h, pad=pad_h, dil=dilation_h,
                om_sigmoid=False, out_nchw=True)

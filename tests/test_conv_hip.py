@@ -231,3 +231,26 @@ def test_dcn_v2_forward_ext_dropin(C, Co, k, s, p, d):
     _close(out, torch.from_numpy(ref), 1e-4)
     with pytest.raises(RuntimeError):
         dcn_v2_ext.dcn_v2_forward(t[0].cpu(), *t[1:], k, k, s, s, p, p, d, d, 1)
+
+
+@pytest.mark.parametrize("cin,cout,hw,B", [(16, 64, (8, 16), 1), (64, 64, (20, 28), 3), (32, 27, (16, 16), 2),
+                                           (48, 128, (9, 35), 2), (128, 192, (16, 16), 2)])
+def test_conv3x3_patch_kernel(cin, cout, hw, B):
+    """LDS-resident halo-patch kernel (tile=3) for 3x3/s1/p1: edges, ragged tiles, residual, all N tiles;
+    must agree with the generic implicit-GEMM kernel and the torch-CPU reference."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    H, W = hw
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bn = _rand_bn(g, cout)
+    res = torch.randn(B, cout, H, W, generator=g)
+    ref = F.relu(_ref_bn(F.conv2d(x, w, None, 1, 1), bn) + res)
+    wp = ops.pack_conv_weight(w.cuda())
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    cst = wp.shape[0] if cout == 27 else cout
+    out = torch.full((B, H, W, cst), float("nan"), device="cuda")
+    resn = torch.zeros(B, H, W, cst)
+    resn[..., :cout] = res.permute(0, 2, 3, 1)
+    ops.conv2d([_nhwc(x)], wp, sc, sh, out, kh=3, kw=3, stride=1, pad=1, cout=cst, act=ops.ACT_RELU, res=resn.cuda(), tile=3)
+    _close(out[..., :cout].permute(0, 3, 1, 2), ref)
