@@ -9,8 +9,10 @@
 // Patch rows are padded to 384 floats so that the two pixel rows a 32-row MFMA tile spans fall on
 // the same bank pattern (384 = 0 mod 64) and the 20-float pixel stride keeps b128 reads
 // conflict-free.  The chunk's weights for all nine taps sit next to it (Bs[9][BN][20]).
-// Per chunk and wave: 54 ds_read_b128, 144 MFMAs (TM=2,TN=1), two barriers -- versus 9 barriers,
-// 9x the staging traffic before.  Global loads for chunk c+1 are in flight during chunk c.
+// Per chunk and wave (BN=64): 54 ds_read_b128, 144 MFMAs, two barriers -- versus 9 barriers and
+// 9x the staging traffic before.  Fragments are double-buffered in registers (tap t+1 is read
+// while tap t multiplies); global loads for chunk c+1 are in flight during chunk c.
+// MF = 32 uses v_mfma_f32_32x32x2 (BN = 64 / 32); MF = 16 uses 16x16x4 for 16-channel layers.
 #include "igemm.h"
 
 #define P3_TH 8
@@ -22,14 +24,16 @@
 #define P3_PIX4 (P3_PH * P3_PW * 4)        // float4 per patch chunk (720)
 #define P3_ASLOTS ((P3_PIX4 + IG_THREADS - 1) / IG_THREADS)
 
-template <int BN, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(   // LDS admits 2 blocks/CU: allow 256 VGPRs
-const ConvArgs a, int tilesX, int tilesY)
+template <int BN, int WAVES_M, int WAVES_N, int MF>
+__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(const ConvArgs a, int tilesX, int tilesY)
 {
-    constexpr int MF = 32;
-    constexpr int WROWS = P3_TH / WAVES_M;            // output rows per wave (4 or 2)
-    constexpr int TM = WROWS / 2;                     // one 32-row MFMA tile = 2 rows x 16 cols
+    constexpr int G = 64 / MF;                        // k-groups across the wave (2 or 4)
+    constexpr int NH = IG_BK / (4 * G);               // b128 reads per fragment row per chunk (2 or 1)
+    constexpr int RPT = MF / 16;                      // output rows per MFMA tile (2 or 1)
+    constexpr int WROWS = P3_TH / WAVES_M;            // output rows per wave
+    constexpr int TM = WROWS / RPT;
     constexpr int WN = BN / WAVES_N, TN = WN / MF;
+    constexpr int NACC = IgAcc<MF>::N;
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* patch0 = smem;                             // [P3_PATCH]
@@ -47,18 +51,17 @@ const ConvArgs a, int tilesX, int tilesY)
     const int wy0 = (wid / WAVES_N) * WROWS, wn0 = (wid % WAVES_N) * WN;
     const int C = a.srcC[0], ld = a.srcLd[0];
     const float* __restrict__ x = a.src[0];
-    const int g = lane >> 5, il = lane & 31;
+    const int g = lane / MF, il = lane % MF;
 
-    f32x16 acc[TM][TN];
+    typename IgAcc<MF>::type acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < NACC; ++r) acc[i][j][r] = 0.f;
 
-    // ---- staging assignments (fixed per thread) ----
-    // (element offsets fit 32 bits: checked on the host)
+    // ---- staging assignments (fixed per thread; element offsets fit 32 bits: checked on the host)
     int a_goff0, a_goff1, a_goff2, a_lds0, a_lds1, a_lds2;
     {
         int go[P3_ASLOTS], lo[P3_ASLOTS];
@@ -76,8 +79,9 @@ const ConvArgs a, int tilesX, int tilesY)
         a_lds0 = lo[0]; a_lds1 = lo[1]; a_lds2 = lo[2];
     }
     static_assert(P3_ASLOTS == 3, "three patch slots per thread");
-    // weight staging: thread -> fixed (n, q); slot s covers tap s (BN=64) or taps 2s + (tid>>7) (BN=32)
-    constexpr int TPS = IG_THREADS / (BN * 4);        // taps covered by one slot: 1 or 2
+    // weight staging: thread -> fixed (n, q); slot s covers taps TPS*s + b_t0
+    constexpr int TPS = IG_THREADS / (BN * 4);        // taps covered by one slot: 1 (BN=64), 2 (32), 4 (16)
+    constexpr int NBS = (9 + TPS - 1) / TPS;          // slots in use: 9, 5, 3
     const int b_n = (tid >> 2) % BN, b_q = tid & 3, b_t0 = tid / (BN * 4);
     const float* wrow = a.w + (size_t)(n0 + b_n) * a.K + b_q * 4;
     float* bdst = Bs + (b_t0 * BN + b_n) * IG_LDK + b_q * 4;
@@ -93,16 +97,18 @@ const ConvArgs a, int tilesX, int tilesY)
         ar0 = a_goff0 >= 0 ? v0 : zero4;                                                                     \
         ar1 = a_goff1 >= 0 ? v1 : zero4;                                                                     \
         ar2 = a_goff2 >= 0 ? v2 : zero4;                                                                     \
-        b0 = P3_LB(0, c0); b1 = P3_LB(1, c0); b2 = P3_LB(2, c0); b3 = P3_LB(3, c0); b4 = P3_LB(4, c0);       \
-        if (TPS == 1) { b5 = P3_LB(5, c0); b6 = P3_LB(6, c0); b7 = P3_LB(7, c0); b8 = P3_LB(8, c0); }        \
+        b0 = P3_LB(0, c0); b1 = P3_LB(1, c0); b2 = P3_LB(2, c0);                                             \
+        if (NBS > 3) { b3 = P3_LB(3, c0); b4 = P3_LB(4, c0); }                                               \
+        if (NBS > 5) { b5 = P3_LB(5, c0); b6 = P3_LB(6, c0); b7 = P3_LB(7, c0); b8 = P3_LB(8, c0); }         \
     }
 #define P3_STORE(patch)                                                                                      \
     {                                                                                                        \
         if (a_lds0 >= 0) *reinterpret_cast<float4*>((patch) + a_lds0) = ar0;                                \
         if (a_lds1 >= 0) *reinterpret_cast<float4*>((patch) + a_lds1) = ar1;                                \
         if (a_lds2 >= 0) *reinterpret_cast<float4*>((patch) + a_lds2) = ar2;                                \
-        P3_SB(0, b0); P3_SB(1, b1); P3_SB(2, b2); P3_SB(3, b3); P3_SB(4, b4);                                \
-        if (TPS == 1) { P3_SB(5, b5); P3_SB(6, b6); P3_SB(7, b7); P3_SB(8, b8); }                            \
+        P3_SB(0, b0); P3_SB(1, b1); P3_SB(2, b2);                                                            \
+        if (NBS > 3) { P3_SB(3, b3); P3_SB(4, b4); }                                                         \
+        if (NBS > 5) { P3_SB(5, b5); P3_SB(6, b6); P3_SB(7, b7); P3_SB(8, b8); }                             \
     }
 
     // lane's fragment bases: A row il -> pixel (il>>4, il&15) of MFMA tile i; B row il -> channel
@@ -119,13 +125,13 @@ const ConvArgs a, int tilesX, int tilesY)
         const bool more = ci + 1 < nchunk;
         if (more) P3_LOAD((ci + 1) * IG_BK);
         // fragments double-buffered in registers: tap t+1 is read from LDS while tap t multiplies
-        float4 af[2][2][TM], bf[2][2][TN];
+        float4 af[2][NH][TM], bf[2][NH][TN];
 #define P3_FRAG(buf, t)                                                                                      \
-        _Pragma("unroll") for (int h = 0; h < 2; ++h) {                                                      \
+        _Pragma("unroll") for (int h = 0; h < NH; ++h) {                                                     \
             _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                   \
-                af[buf][h][i] = *reinterpret_cast<const float4*>(P + (i * 2 + (t) / 3) * P3_PITCH + ((t) % 3) * IG_LDK + h * 8); \
+                af[buf][h][i] = *reinterpret_cast<const float4*>(P + (i * RPT + (t) / 3) * P3_PITCH + ((t) % 3) * IG_LDK + h * 4 * G); \
             _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                   \
-                bf[buf][h][j] = *reinterpret_cast<const float4*>(Q + ((t) * BN + j * MF) * IG_LDK + h * 8);  \
+                bf[buf][h][j] = *reinterpret_cast<const float4*>(Q + ((t) * BN + j * MF) * IG_LDK + h * 4 * G); \
         }
         P3_FRAG(0, 0)
 #pragma unroll
@@ -133,15 +139,15 @@ const ConvArgs a, int tilesX, int tilesY)
             const int cb = t & 1;
             if (t + 1 < 9) { P3_FRAG(cb ^ 1, t + 1) }
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NH; ++h)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][h][i].x, bf[cb][h][j].x, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][h][i].y, bf[cb][h][j].y, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][h][i].z, bf[cb][h][j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cb][h][i].w, bf[cb][h][j].w, acc[i][j], 0, 0, 0);
+                        acc[i][j] = ig_mfma<MF>(af[cb][h][i].x, bf[cb][h][j].x, acc[i][j]);
+                        acc[i][j] = ig_mfma<MF>(af[cb][h][i].y, bf[cb][h][j].y, acc[i][j]);
+                        acc[i][j] = ig_mfma<MF>(af[cb][h][i].z, bf[cb][h][j].z, acc[i][j]);
+                        acc[i][j] = ig_mfma<MF>(af[cb][h][i].w, bf[cb][h][j].w, acc[i][j]);
                     }
         }
         __syncthreads();                // all waves are done with Bs and the patch
@@ -154,9 +160,9 @@ const ConvArgs a, int tilesX, int tilesY)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int rowl = ig_row<32>(r, lane);
-            const int yy = y0 + wy0 + i * 2 + (rowl >> 4), xx = x0 + (rowl & 15);
+        for (int r = 0; r < NACC; ++r) {
+            const int rowl = ig_row<MF>(r, lane);     // row of the MFMA tile: pixel (rowl>>4, rowl&15)
+            const int yy = y0 + wy0 + i * RPT + (rowl >> 4), xx = x0 + (rowl & 15);
             if (yy >= a.H || xx >= a.W) continue;
             const size_t opix = ((size_t)b * a.H + yy) * a.W + xx;
             float* orow = a.out + opix * a.outLd;
@@ -176,10 +182,10 @@ const ConvArgs a, int tilesX, int tilesY)
     }
 }
 
-template <int BN, int WAVES_M, int WAVES_N>
+template <int BN, int WAVES_M, int WAVES_N, int MF>
 static int launch_patch(const ConvArgs& a, hipStream_t s)
 {
-    auto kern = conv3x3_patch_kernel<BN, WAVES_M, WAVES_N>;
+    auto kern = conv3x3_patch_kernel<BN, WAVES_M, WAVES_N, MF>;
     const int smem = (P3_PATCH + 9 * BN * IG_LDK) * 4;
     static bool attr = false;
     if (!attr && smem > 64 * 1024) {
@@ -198,8 +204,10 @@ int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s)
 {
     const bool ok = !in_nchw && a.nsrc == 1 && a.kh == 3 && a.kw == 3 && a.sy == 1 && a.sx == 1 && a.py == 1 && a.px == 1 &&
                     !a.outNCHW && a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Ho == a.H && a.Wo == a.W &&
-                    a.OH == a.H && a.OW == a.W && a.srcC[0] % 16 == 0 && (a.ldw % 64 == 0 || a.ldw == 32);
+                    a.OH == a.H && a.OW == a.W && a.srcC[0] % 16 == 0 && (a.ldw % 64 == 0 || a.ldw == 32 || a.ldw == 16) &&
+                    (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
     if (!ok) return -1;
-    if (a.ldw == 32) return launch_patch<32, 4, 1>(a, s);
-    return launch_patch<64, 2, 2>(a, s);
+    if (a.ldw == 16) return launch_patch<16, 4, 1, 16>(a, s);
+    if (a.ldw == 32) return launch_patch<32, 4, 1, 32>(a, s);
+    return launch_patch<64, 2, 2, 32>(a, s);
 }

@@ -1,0 +1,143 @@
+// 7x7 stem convolution on the 3-channel NCHW network input (gfx950, fp32 MFMA 16x16x4).
+//
+//   DLA-34   base_layer: Conv2d(3,16,k7,s1,p3)+BN+ReLU  (pose_dla_dcn.py:228-232)  @512x512
+//   ResNet-50 conv1    : Conv2d(3,64,k7,s2,p3)+BN+ReLU  (msra_resnet.py:118-121)
+// K = 147 is tiny and the input has 3 planes, so the generic im2col path (16 scalar gathers per
+// thread per k-step) ran at 19 TFLOP/s.  Here the block stages the 3 x (rows+6) x (cols+6) input
+// window once (coalesced row reads straight from NCHW), and MFMA A-fragments are read from it:
+// the k axis is re-ordered as k = ((c*7 + ky)*8 + kx) (kx padded 7 -> 8 with zero weights), so the
+// 4 consecutive k a lane feeds to 4 successive 16x16x4 MFMAs are 4 consecutive floats of one patch
+// row.  Weights for all 11 k16-steps sit in LDS ([11][NOUT][20], b128 reads).  Output is NHWC.
+#include "igemm.h"
+
+#define S7_STEPS 11          // 21 (c,ky) rows, 2 per k16-step, last half-step zero
+#define S7_K (S7_STEPS * 16)
+
+template <int NOUT, int S, int TH, int TW>
+__global__ __launch_bounds__(IG_THREADS) void stem7x7_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              float* __restrict__ out, int B, int H, int W, int Ho, int Wo,
+                                                              int outLd, int relu, int tilesX, int tilesY)
+{
+    constexpr int PH = (TH - 1) * S + 7, PWr = (TW - 1) * S + 7, PW = (PWr + 3) & ~3;   // patch rows / padded pitch
+    constexpr int TN = NOUT / 16;
+    constexpr int ROWS_W = TH / 4;                 // output rows per wave
+    constexpr int TM = ROWS_W * (TW / 16);         // 16-pixel MFMA tiles per wave
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* patch = smem;                           // [3][PH][PW]
+    float* Bs = smem + ((3 * PH * PW + 3) & ~3);   // [S7_STEPS][NOUT][IG_LDK]
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int t_ = blockIdx.x;
+    const int tx = t_ % tilesX; t_ /= tilesX;
+    const int ty = t_ % tilesY;
+    const int b = t_ / tilesY;
+    const int oy0 = ty * TH, ox0 = tx * TW;
+    const int iy0 = oy0 * S - 3, ix0 = ox0 * S - 3;
+
+    // ---- stage the input window (zero padded) and the packed weights
+    for (int idx = tid; idx < 3 * PH * PW; idx += IG_THREADS) {
+        const int px = idx % PW, r = idx / PW, py = r % PH, c = r / PH;
+        const int iy = iy0 + py, ix = ix0 + px;
+        float v = 0.f;
+        if (px < PWr && iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[((size_t)(b * 3 + c) * H + iy) * W + ix];
+        patch[idx] = v;
+    }
+    for (int idx = tid; idx < S7_STEPS * NOUT * 4; idx += IG_THREADS) {
+        const int q = idx & 3, n = (idx >> 2) % NOUT, st = idx / (NOUT * 4);
+        *reinterpret_cast<float4*>(Bs + (st * NOUT + n) * IG_LDK + q * 4) =
+            *reinterpret_cast<const float4*>(w + (size_t)n * S7_K + st * 16 + q * 4);
+    }
+    __syncthreads();
+
+    f32x4 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int g = lane >> 4, il = lane & 15;
+    // lane's A base inside a (c,ky) patch row: column of pixel il plus its 4-wide kx group
+    const int a_col = il * S + (g & 1) * 4;
+#pragma unroll 1
+    for (int st = 0; st < S7_STEPS; ++st) {
+        const int row = 2 * st + (g >> 1);           // (c*7 + ky); row 21 (last half-step) has zero weights
+        const int c = row / 7, ky = row - c * 7;
+        const bool rok = row < 21;
+        float4 bf[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + (st * NOUT + j * 16 + il) * IG_LDK + g * 4);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int orow = wid * ROWS_W + i / (TW / 16), ocol = (i % (TW / 16)) * 16;
+            const float* p = patch + ((rok ? c : 0) * PH + orow * S + (rok ? ky : 0)) * PW + ocol * S + a_col;
+            const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bf[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bf[j].w, acc[i][j], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- epilogue: folded BN + ReLU, NHWC
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int oy = oy0 + wid * ROWS_W + i / (TW / 16);
+        const int oxb = ox0 + (i % (TW / 16)) * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ox = oxb + g * 4 + r;
+            if (oy >= Ho || ox >= Wo) continue;
+            float* orow = out + ((size_t)(b * Ho + oy) * Wo + ox) * outLd;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = j * 16 + il;
+                float v = acc[i][j][r] * scale[n] + shift[n];
+                if (relu) v = fmaxf(v, 0.f);
+                orow[n] = v;
+            }
+        }
+    }
+}
+
+template <int NOUT, int S, int TH, int TW>
+static int launch_stem(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H, int W,
+                       int outLd, int relu, hipStream_t s)
+{
+    constexpr int PH = (TH - 1) * S + 7, PWr = (TW - 1) * S + 7, PW = (PWr + 3) & ~3;
+    const int Ho = (H + 6 - 7) / S + 1, Wo = (W + 6 - 7) / S + 1;
+    const int smem = (((3 * PH * PW + 3) & ~3) + S7_STEPS * NOUT * IG_LDK) * 4;
+    auto kern = stem7x7_kernel<NOUT, S, TH, TW>;
+    static bool attr = false;
+    if (!attr && smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) { cp_set_error("stem7x7: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
+        attr = true;
+    }
+    const int tilesX = cp_cdiv(Wo, TW), tilesY = cp_cdiv(Ho, TH);
+    hipLaunchKernelGGL(kern, dim3((unsigned)(B * tilesX * tilesY)), dim3(IG_THREADS), smem, s, x, w, scale, shift, out, B, H, W, Ho,
+                       Wo, outLd, relu, tilesX, tilesY);
+    return 0;
+}
+
+// x: NCHW [B,3,H,W]; w: packed [NOUT][176] with k = ((c*7+ky)*8 + kx) (see ops.pack_stem7_weight);
+// out: NHWC [B,Ho,Wo,outLd].  Cout in {16, 64}, stride in {1, 2}, pad 3.
+extern "C" int cp_stem7x7_f32(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H,
+                              int W, int Cout, int stride, int outLd, int relu, void* stream)
+{
+    CP_CHECK_ARG(x && w && scale && shift && out, "stem7x7: null pointer");
+    CP_CHECK_ARG(outLd >= Cout, "stem7x7: outLd < Cout");
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if (Cout == 16 && stride == 1) rc = launch_stem<16, 1, 8, 64>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
+    else if (Cout == 64 && stride == 2) rc = launch_stem<64, 2, 8, 32>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
+    else if (Cout == 64 && stride == 1) rc = launch_stem<64, 1, 8, 32>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
+    else if (Cout == 16 && stride == 2) rc = launch_stem<16, 2, 8, 64>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
+    else { cp_set_error("stem7x7: unsupported Cout=%d stride=%d", Cout, stride); return 1; }
+    if (rc) return rc;
+    CP_CHECK_LAUNCH("stem7x7_kernel");
+    return 0;
+}

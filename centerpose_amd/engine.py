@@ -56,6 +56,13 @@ class PlanBuilder(nets.Graph):
         x = xs[0]
         Ho, Wo = (x.H + 2 * pad - k) // stride + 1, (x.W + 2 * pad - k) // stride + 1
         out = self.buf(Ho, Wo, co)
+        if stem and k == 7 and pad == 3 and co in (16, 64) and res is None and bn:
+            # dedicated 7x7 stem kernel (NCHW 3-channel input window staged once in LDS)
+            wp7 = ops.pack_stem7_weight(self.w(conv + ".weight"))
+            sc7, sh7 = ops.fold_bn(co, self.bn(bn), self.w(conv + ".bias") if bias else None, self.dev)
+            xin, ot7 = xs[0].t, out.t
+            self.add("conv", conv, 2 * Ho * Wo * co * 3 * 49, lambda: ops.stem7x7(xin, wp7, sc7, sh7, ot7, stride, relu))
+            return out
         wp = ops.pack_conv_weight(self.w(conv + ".weight"), stem=stem)
         sc, sh = ops.fold_bn(co, self.bn(bn) if bn else None, self.w(conv + ".bias") if bias else None, self.dev)
         srcs = [a.t for a in xs]

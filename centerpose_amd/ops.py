@@ -224,3 +224,23 @@ def pack_deconv4_subpixel(w, py, px):
     sub = w[:, :, kys][:, :, :, kxs]                      # [Ci,Co,2,2] indexed by (ty,tx)
     wp = sub.permute(1, 2, 3, 0).reshape(Co, 4 * Ci)      # k = (ty*2+tx)*Ci + c
     return pad_rows(wp.float().contiguous(), ldw_for(Co))
+
+
+def pack_stem7_weight(w):
+    """[Co,3,7,7] -> [Co,176]: k = (c*7 + ky)*8 + kx, kx padded 7 -> 8 and K padded 168 -> 176 with zeros
+    (layout consumed by cp_stem7x7_f32: 4 consecutive k == 4 consecutive floats of one input row)."""
+    Co, Ci, kh, kw = w.shape
+    assert (Ci, kh, kw) == (3, 7, 7)
+    wp = torch.zeros((Co, 22, 8), dtype=torch.float32, device=w.device)
+    wp[:, :21, :7] = w.reshape(Co, 21, 7)
+    return wp.reshape(Co, 176).contiguous()
+
+
+def stem7x7(x, wp, scale, shift, out, stride, relu=True):
+    """7x7 / pad 3 stem on the NCHW 3-channel input -> NHWC out."""
+    B, C, H, W = x.shape
+    assert C == 3 and x.is_contiguous()
+    rc = _lib.lib().cp_stem7x7_f32(_lib.ptr(_lib.f32(x)), _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift), _lib.vptr(out), B, H, W,
+                                   wp.shape[0], stride, _ld(out), 1 if relu else 0, _lib.stream())
+    _lib.check(rc, "cp_stem7x7_f32")
+    return out

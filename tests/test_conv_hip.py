@@ -233,7 +233,7 @@ def test_dcn_v2_forward_ext_dropin(C, Co, k, s, p, d):
         dcn_v2_ext.dcn_v2_forward(t[0].cpu(), *t[1:], k, k, s, s, p, p, d, d, 1)
 
 
-@pytest.mark.parametrize("cin,cout,hw,B", [(16, 64, (8, 16), 1), (64, 64, (20, 28), 3), (32, 27, (16, 16), 2),
+@pytest.mark.parametrize("cin,cout,hw,B", [(16, 16, (24, 40), 2), (16, 64, (8, 16), 1), (64, 64, (20, 28), 3), (32, 27, (16, 16), 2),
                                            (48, 128, (9, 35), 2), (128, 192, (16, 16), 2)])
 def test_conv3x3_patch_kernel(cin, cout, hw, B):
     """LDS-resident halo-patch kernel (tile=3) for 3x3/s1/p1: edges, ragged tiles, residual, all N tiles;
@@ -254,3 +254,18 @@ def test_conv3x3_patch_kernel(cin, cout, hw, B):
     resn[..., :cout] = res.permute(0, 2, 3, 1)
     ops.conv2d([_nhwc(x)], wp, sc, sh, out, kh=3, kw=3, stride=1, pad=1, cout=cst, act=ops.ACT_RELU, res=resn.cuda(), tile=3)
     _close(out[..., :cout].permute(0, 3, 1, 2), ref)
+
+
+@pytest.mark.parametrize("cout,s,hw", [(16, 1, (40, 72)), (64, 2, (37, 70)), (16, 1, (512, 512)), (64, 2, (128, 96))])
+def test_stem7x7_kernel(cout, s, hw):
+    """dedicated 7x7 stem (pose_dla_dcn.py:228-232 / msra_resnet.py:118-121) vs torch-CPU."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(cout + s)
+    x = torch.randn(2, 3, *hw, generator=g)
+    w = torch.randn(cout, 3, 7, 7, generator=g) * 0.1
+    bn = _rand_bn(g, cout)
+    ref = F.relu(_ref_bn(F.conv2d(x, w, None, s, 3), bn))
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    out = torch.full((2, ref.shape[2], ref.shape[3], cout), float("nan"), device="cuda")
+    ops.stem7x7(x.cuda(), ops.pack_stem7_weight(w.cuda()), sc, sh, out, s)
+    _close(out.permute(0, 3, 1, 2), ref)
