@@ -31,8 +31,9 @@ enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_SIGMOID = 2 };
  *   lib/models/backbones/pose_higher_hrnet.py:98-235, lib/models/heads/keypoint.py:14-42,
  *   and the in-place sigmoid of lib/detectors/multi_pose.py:35-37.
  * out = act( (sum over up to 4 channel-concatenated sources of conv(src)) * scale + shift [+ res] ).
- * w: packed weights [K][ldw], k = (ky*kw + kx)*Ctot + c  (inNCHW stem: k = (c*kh + ky)*kw + kx, K padded
- * to a multiple of 16 with zero rows), ldw = Cout padded to 16 / 32 / a multiple of 64 with zero columns;
+ * w: packed weights [ldw][K] (n-major, k contiguous), k = (ky*kw + kx)*Ctot + c  (inNCHW stem:
+ * k = (c*kh + ky)*kw + kx, K padded to a multiple of 16 with zeros), ldw = Cout padded to 16 / 32 / a
+ * multiple of 64 with zero rows;  3x3/s1/p1 single-source NHWC launches use the LDS halo-patch kernel;
  * scale/shift: [ldw] (folded BN or 1/bias).  res: NHWC residual with pixel stride resLd, or NULL. */
 typedef struct cp_conv_desc {
     int nsrc;                 /* 1..4 sources */
@@ -57,7 +58,7 @@ int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w
  * src/cuda/dcn_v2_im2col_cuda.cu:25-54,125-195) plus the BN + ReLU of DeformConv (pose_dla_dcn.py:345-348).
  * x: NHWC [B,H,W,srcLd]; om: NHWC [B,Ho,Wo,omLd] with ch 2k = dy_k, 2k+1 = dx_k, 2*kh*kw + k = mask_k
  * (logits if omSigmoid, as produced by conv_offset_mask, dcn_v2.py:117-121; already-sigmoided otherwise);
- * w: [kh*kw*C][ldw]; deformable_group == 1 (the only value the reference uses). */
+ * w: [ldw][kh*kw*C]; deformable_group == 1 (the only value the reference uses). */
 typedef struct cp_dcn_desc {
     int B, H, W, C, srcLd;
     int Ho, Wo;
@@ -69,6 +70,13 @@ typedef struct cp_dcn_desc {
 } cp_dcn_desc;
 int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* om, const float* w, const float* scale,
                   const float* shift, float* out, void* stream);
+
+/* ---- 7x7 / pad 3 stem on the NCHW 3-channel network input ----------------------------------------
+ * Replaces base_layer Conv2d(3,16,k7,s1,p3)+BN+ReLU (pose_dla_dcn.py:228-232) and conv1 Conv2d(3,64,k7,s2,p3)
+ * +BN+ReLU (msra_resnet.py:118-121).  x: NCHW [B,3,H,W]; w: [Cout][176] with k = ((c*7+ky)*8 + kx) (kx padded
+ * to 8, zeros); out: NHWC [B,Ho,Wo,outLd].  (Cout, stride) in {16,64} x {1,2}. */
+int cp_stem7x7_f32(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H, int W,
+                   int Cout, int stride, int outLd, int relu, void* stream);
 
 /* ---- bandwidth-bound NHWC helpers --------------------------------------------------------------- */
 /* nn.MaxPool2d (pose_dla_dcn.py:197-198 k2 s2; msra_resnet.py:123 k3 s2 p1) */
