@@ -42,8 +42,17 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(const Conv
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int NT = a.ldw / BN;
     const int tile = ig_xcd_remap(blockIdx.x, gridDim.x);
-    const int nt = tile % NT;
-    int sp_ = tile / NT;
+    // tile order: (n-tile group of <= 8) outermost, then spatial tile, then n-tile inside the group.
+    // An XCD works on a contiguous tile range, so its 4 MiB L2 has to hold the weights of only 8
+    // n-tiles (head: 1.2 MB instead of all 3.5 MB) while the 8 blocks sharing a patch run back to back.
+    int nt, sp_;
+    if (NT <= 8) { nt = tile % NT; sp_ = tile / NT; }
+    else {
+        const int SP = gridDim.x / NT;                 // spatial tiles
+        const int full = (NT / 8) * 8 * SP;            // tiles covered by complete groups
+        if (tile < full) { const int grp = tile / (8 * SP), rem = tile - grp * 8 * SP; sp_ = rem >> 3; nt = grp * 8 + (rem & 7); }
+        else { const int gs = NT - (NT / 8) * 8, rem = tile - full; sp_ = rem / gs; nt = (NT / 8) * 8 + rem % gs; }
+    }
     const int tx = sp_ % tilesX; sp_ /= tilesX;
     const int ty = sp_ % tilesY;
     const int b = sp_ / tilesY;
@@ -200,7 +209,7 @@ static int launch_patch(const ConvArgs& a, hipStream_t s)
 }
 
 // eligibility + dispatch; returns -1 if the shape is not handled here (caller falls back to the generic kernel)
-int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s)
+int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s, int variant)
 {
     const bool ok = !in_nchw && a.nsrc == 1 && a.kh == 3 && a.kw == 3 && a.sy == 1 && a.sx == 1 && a.py == 1 && a.px == 1 &&
                     !a.outNCHW && a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Ho == a.H && a.Wo == a.W &&
@@ -208,6 +217,9 @@ int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s)
                     (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
     if (!ok) return -1;
     if (a.ldw == 16) return launch_patch<16, 4, 1, 16>(a, s);
-    if (a.ldw == 32) return launch_patch<32, 4, 1, 32>(a, s);
+    // measured (MI355X): with <= 4 channel chunks per tile the per-tile prologue/epilogue dominates and the
+    // 32-channel variant (38 KB LDS -> 4 blocks/CU instead of 2) wins: head 3x3 106 -> 117 TFLOP/s;
+    // from 128 input channels on, the 64-channel variant's better LDS-read/MFMA ratio wins.
+    if (a.ldw == 32 || variant == 32 || (variant == 0 && a.srcC[0] <= 64)) return launch_patch<32, 4, 1, 32>(a, s);
     return launch_patch<64, 2, 2, 32>(a, s);
 }

@@ -230,14 +230,14 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
     hipStream_t s = (hipStream_t)stream;
 
     int tile = d->tile;
-    if (tile == 0 || tile == 3) {   // 3x3/s1/p1 NHWC: LDS-resident halo patch kernel (conv3x3_patch.hip)
-        const int prc = cp_launch_conv3x3_patch(a, d->inNCHW, s);
+    if (tile == 0 || tile == 3 || tile == 332) {   // 3x3/s1/p1 NHWC: LDS-resident halo patch kernel (conv3x3_patch.hip)
+        const int prc = cp_launch_conv3x3_patch(a, d->inNCHW, s, tile == 332 ? 32 : 0);
         if (prc >= 0) {
             if (prc) return prc;
             CP_CHECK_LAUNCH("conv3x3_patch_kernel");
             return 0;
         }
-        CP_CHECK_ARG(tile == 0, "conv2d: tile=3 (patch kernel) requested for an ineligible shape");
+        CP_CHECK_ARG(tile == 0, "conv2d: patch kernel requested for an ineligible shape");
     }
     if (tile == 0) {
         // heuristic: N tile from the padded channel count, M tile from how many blocks fill 256 CUs

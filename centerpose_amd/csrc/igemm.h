@@ -59,7 +59,7 @@ struct ConvArgs {
 };
 
 // conv3x3_patch.hip: returns -1 when the shape is not eligible, else 0 / error code
-int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s);
+int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s, int variant = 0);
 
 // XCD-aware, bijective remap of the linear block id: blocks that are consecutive in the
 // remapped order (and share the same activation rows) land on the same XCD / L2.
