@@ -164,8 +164,49 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(const Conv
         __syncthreads();
     }
 
-    // ---- epilogue: scale/shift (+residual) + activation, NHWC stores coalesced along n ----
+    // ---- epilogue: scale/shift (+residual) + activation ----
     const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
+    const bool vec_ok = ((a.outLd | a.Cout) & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
+                        (!a.res || ((a.resLd & 3) == 0 && (((size_t)a.res) & 15) == 0));
+    if (vec_ok) {
+        // vectorised: C tile through LDS (Cs[pixel][n], the main-loop buffers are dead after the last
+        // barrier), then float4 residual loads / stores along n
+        float* Cs = smem;
+        constexpr int LDC = BN + 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < NACC; ++r)
+                    Cs[((wy0 + i * RPT) * P3_TW + ig_row<MF>(r, lane)) * LDC + wn0 + j * MF + il] = acc[i][j][r];
+        __syncthreads();
+        constexpr int NV = BN / 4;
+#pragma unroll
+        for (int s2 = 0; s2 < P3_TH * P3_TW * NV / IG_THREADS; ++s2) {
+            const int idx = tid + s2 * IG_THREADS;
+            const int pl = idx / NV, c4 = idx - pl * NV;
+            const int yy = y0 + (pl >> 4), xx = x0 + (pl & 15), n = n0 + c4 * 4;
+            if (yy < a.H && xx < a.W && n < a.Cout) {
+                const size_t opix = ((size_t)b * a.H + yy) * a.W + xx;
+                float4 v = *reinterpret_cast<const float4*>(Cs + pl * LDC + c4 * 4);
+                const float4 sc = *reinterpret_cast<const float4*>(a.scale + n);
+                const float4 sh = *reinterpret_cast<const float4*>(a.shift + n);
+                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                if (a.res) {
+                    const float4 rr = *reinterpret_cast<const float4*>(a.res + opix * a.resLd + n);
+                    v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+                }
+                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                else if (sigm) {
+                    v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
+                    v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
+                }
+                *reinterpret_cast<float4*>(a.out + opix * a.outLd + n) = v;
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll

@@ -164,10 +164,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t s)
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
     auto kern = igemm_conv_kernel<BM, BN, WAVES_M, WAVES_N, MF, STEM>;
     if (a.ldw % BN != 0) { cp_set_error("conv2d: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
-    const int smem = a.outNCHW ? T::SMEM : T::MAIN_BYTES;
+    const int smem = a.outNCHW ? T::SMEM : T::NHWC_BYTES;
     static bool attr = false;
     if (!attr && smem > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM);
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM > T::NHWC_BYTES ? T::SMEM : T::NHWC_BYTES);
         attr = true;
     }
     const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN);

@@ -149,7 +149,8 @@ static int launch_dcn(const ConvArgs& a, hipStream_t s)
     auto kern = dcn_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MF>;
     if (a.ldw % BN != 0) { cp_set_error("dcn: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
     const int main_bytes = T::MAIN_BYTES + DCN_MAX_TAPS * BM * 20;
-    const int smem = (a.outNCHW && T::EPI_BYTES > main_bytes) ? T::EPI_BYTES : main_bytes;
+    const int epi = a.outNCHW ? T::EPI_BYTES : T::EPV_BYTES;
+    const int smem = epi > main_bytes ? epi : main_bytes;
     static bool attr = false;
     if (!attr && smem > 64 * 1024) {
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
