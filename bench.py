@@ -122,6 +122,15 @@ def main():
                 "all_kernels_ms_per_step": round(all_ms, 3),
                 "algorithmic_gflop_per_image": round(eng.flops_per_image / 1e9, 2),
                 "end_to_end_tflops": round(eng.flops_per_image * value / world / 1e12, 2)}
+        # HBM traffic per launch of the same kernel family from the committed rocprofv3 PMC passes
+        # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; collected offline, see profiles/README.md)
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
+            if args.arch == "dla_34" and B == 16:
+                roof["traffic"] = pmc["traffic_bytes_per_launch_avg"]
+                roof["traffic_unit"] = "bytes per launch (avg over the %d GEMM launches of a step)" % pmc["gemm_launches_per_step"]
+        except (OSError, KeyError, ValueError):
+            pass
         line = {"metric": "images/sec end-to-end (backbone+decode), DLA-34 512x512", "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
