@@ -19,7 +19,7 @@
 #define DCN_MAX_TAPS 9
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MF>
-__global__ __launch_bounds__(IG_THREADS) void dcn_igemm_kernel(const ConvArgs a)
+__global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs a)
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
     extern __shared__ __attribute__((aligned(16))) float smem[];

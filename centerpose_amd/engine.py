@@ -134,27 +134,43 @@ class PlanBuilder(nets.Graph):
         return out
 
     def emit_head(self, feat, p, hc):
-        """six [3x3 conv + bias + ReLU] merged into one launch (Cout = 6*hc, shared A tile), then six
-        1x1 convs on channel slices writing the reference's NCHW outputs; hm / hm_hp get their
-        sigmoid (multi_pose.py:35-37) in the epilogue."""
+        """Per head: [3x3 conv + bias + ReLU] -> ONE shared mid buffer -> 1x1 conv writing the reference's
+        NCHW output (hm / hm_hp get their sigmoid, multi_pose.py:35-37, in the epilogue).  Running each
+        head's 1x1 right after its 3x3 on the same (B*H*W*hc*4 B = 268 MB at B=16) buffer keeps the
+        intermediate resident in the 256 MiB Infinity Cache instead of streaming 1.6 GB through HBM."""
         H, W = feat.H, feat.W
-        mid = self.buf(H, W, 6 * hc)
-        w3 = torch.cat([self.w("%s.%s.0.weight" % (p, h)) for h, _ in nets.HEADS], 0)
-        b3 = torch.cat([self.w("%s.%s.0.bias" % (p, h)) for h, _ in nets.HEADS], 0)
-        wp3 = ops.pack_conv_weight(w3)
-        sc3, sh3 = ops.fold_bn(6 * hc, None, b3, self.dev)
-        ft, mt = feat.t, mid.t
-
-        def fn3():
-            ops.conv2d([ft], wp3, sc3, sh3, mt, kh=3, kw=3, stride=1, pad=1, cout=6 * hc, act=ops.ACT_RELU)
-        self.add("conv", p + ".*.0", 2 * H * W * 6 * hc * feat.C * 9, fn3)
+        per_head = self.B * H * W * hc * 4 <= 300 * (1 << 20) and hc >= 64
+        ft = feat.t
         outs = []
+        if per_head:
+            mid = self.buf(H, W, hc)
+            mt = mid.t
+        else:
+            mid = self.buf(H, W, 6 * hc)
+            mt = mid.t
+            w3 = torch.cat([self.w("%s.%s.0.weight" % (p, h)) for h, _ in nets.HEADS], 0)
+            b3 = torch.cat([self.w("%s.%s.0.bias" % (p, h)) for h, _ in nets.HEADS], 0)
+            wp3 = ops.pack_conv_weight(w3)
+            sc3, sh3 = ops.fold_bn(6 * hc, None, b3, self.dev)
+
+            def fn3():
+                ops.conv2d([ft], wp3, sc3, sh3, mt, kh=3, kw=3, stride=1, pad=1, cout=6 * hc, act=ops.ACT_RELU)
+            self.add("conv", p + ".*.0", 2 * H * W * 6 * hc * feat.C * 9, fn3)
         for i, (h, n) in enumerate(nets.HEADS):
             o = torch.empty((self.B, n, H, W), dtype=torch.float32, device=self.dev)
             wp = ops.pack_conv_weight(self.w("%s.%s.2.weight" % (p, h)))
             sc, sh = ops.fold_bn(n, None, self.w("%s.%s.2.bias" % (p, h)), self.dev)
             act = ops.ACT_SIGMOID if h in self.sigmoid_heads else ops.ACT_NONE
-            sl = mt[..., i * hc:(i + 1) * hc]
+            if per_head:
+                wp3h = ops.pack_conv_weight(self.w("%s.%s.0.weight" % (p, h)))
+                sc3h, sh3h = ops.fold_bn(hc, None, self.w("%s.%s.0.bias" % (p, h)), self.dev)
+
+                def fn3h(wp3h=wp3h, sc3h=sc3h, sh3h=sh3h):
+                    ops.conv2d([ft], wp3h, sc3h, sh3h, mt, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU)
+                self.add("conv", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9, fn3h)
+                sl = mt
+            else:
+                sl = mt[..., i * hc:(i + 1) * hc]
 
             def fn(sl=sl, wp=wp, sc=sc, sh=sh, o=o, n=n, act=act):
                 ops.conv2d([sl], wp, sc, sh, o, kh=1, kw=1, cout=n, act=act, out_nchw=True)
