@@ -58,6 +58,8 @@ class BaseDetector(object):
         self.scales = cfg.TEST.TEST_SCALES
         self.cfg = cfg
         self.pause = True
+        self.device_preprocess = True     # HIP warp/normalise kernel for uint8 HxWx3 inputs
+        self.device_postprocess = True    # HIP inverse-affine kernel, one D2H copy of the mapped dets
 
     def pre_process(self, image, scale, meta=None):
         """base_detector.py:32-62 (image: HxWx3 uint8/float BGR array)."""
@@ -75,12 +77,27 @@ class BaseDetector(object):
         trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
         if (new_height, new_width) != (height, width):     # cv2.resize stand-in: fold the resize into the warp
             trans_input = trans_input @ np.array([[width / new_width, 0, 0], [0, height / new_height, 0], [0, 0, 1]])
-        inp_image = _warp_affine_bilinear(image, trans_input, inp_width, inp_height)
-        inp_image = ((inp_image / 255. - self.mean) / self.std).astype(np.float32)
-        images = inp_image.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width)
-        if self.cfg.TEST.FLIP_TEST:
-            images = np.concatenate((images, images[:, :, :, ::-1]), axis=0)
-        images = torch.from_numpy(np.ascontiguousarray(images))
+        if self.device_preprocess and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3:
+            # warp + normalise + HWC->CHW (+ mirrored twin) in one HIP kernel
+            import ctypes
+            Mi = np.ascontiguousarray(np.linalg.inv(np.vstack([trans_input, [0, 0, 1]]))[:2], np.float32)   # out px -> src px
+            img_d = torch.from_numpy(np.ascontiguousarray(image)).cuda()
+            nb = 2 if self.cfg.TEST.FLIP_TEST else 1
+            images = torch.empty((nb, 3, inp_height, inp_width), dtype=torch.float32, device="cuda")
+            mean = np.ascontiguousarray(self.mean.reshape(3), np.float32)
+            std = np.ascontiguousarray(self.std.reshape(3), np.float32)
+            rc = _lib.lib().cp_preprocess_u8_f32(ctypes.c_void_p(img_d.data_ptr()), height, width,
+                                                  Mi.ctypes.data_as(ctypes.c_void_p), _lib.ptr(images), inp_height, inp_width,
+                                                  mean.ctypes.data_as(ctypes.c_void_p), std.ctypes.data_as(ctypes.c_void_p),
+                                                  1 if nb == 2 else 0, _lib.stream())
+            _lib.check(rc, "cp_preprocess_u8_f32")
+        else:
+            inp_image = _warp_affine_bilinear(image, trans_input, inp_width, inp_height)
+            inp_image = ((inp_image / 255. - self.mean) / self.std).astype(np.float32)
+            images = inp_image.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width)
+            if self.cfg.TEST.FLIP_TEST:
+                images = np.concatenate((images, images[:, :, :, ::-1]), axis=0)
+            images = torch.from_numpy(np.ascontiguousarray(images))
         meta = {"c": c, "s": s, "out_height": inp_height // self.cfg.MODEL.DOWN_RATIO,
                 "out_width": inp_width // self.cfg.MODEL.DOWN_RATIO}
         return images, meta
@@ -192,7 +209,16 @@ class MultiPoseDetector(BaseDetector):
         return outputs, dets
 
     def post_process(self, dets, meta, scale=1):
-        """multi_pose.py:62-71"""
+        """multi_pose.py:62-71 (batch-1 by construction, like the reference)."""
+        if self.device_postprocess and dets.is_cuda and dets.shape[2] == 56 and self.num_classes == 1:
+            flat = dets.detach().reshape(1, -1, 56).contiguous()
+            trans = get_affine_transform(meta["c"], meta["s"], 0, (meta["out_width"], meta["out_height"]), inv=1)
+            td = torch.from_numpy(np.ascontiguousarray(trans, np.float64)).cuda()
+            out = torch.empty_like(flat)
+            rc = _lib.lib().cp_transform_dets_f32(_lib.ptr(flat), _lib.ptr(out), _lib.c_void_p(td.data_ptr()), 1, flat.shape[1], 17,
+                                                  _lib.c_float(float(scale)), _lib.stream())
+            _lib.check(rc, "cp_transform_dets_f32")
+            return {1: out[0].cpu().numpy()}
         dets = dets.detach().cpu().numpy().reshape(1, -1, dets.shape[2])
         dets = multi_pose_post_process(dets.copy(), [meta["c"]], [meta["s"]], meta["out_height"], meta["out_width"])
         for j in range(1, self.num_classes + 1):

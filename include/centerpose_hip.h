@@ -96,6 +96,17 @@ int cp_fill_f32(float* p, float v, long long n, void* stream);
  * perm: device int[J] joint permutation (NULL for mode 0). */
 int cp_flip_merge_f32(const float* in, float* out, int C, int H, int W, int mode, const int* perm, void* stream);
 
+/* ---- device pre-/post-processing ---------------------------------------------------
+ * cp_preprocess_u8_f32: cv2.warpAffine(INTER_LINEAR, border 0) + (x/255 - mean)/std + HWC->CHW of
+ *   lib/detectors/base_detector.py:46-56.  img: DEVICE uint8 [H,W,3]; M: HOST float[6], the 2x3 matrix mapping
+ *   an OUTPUT pixel to source coordinates (inverse of the matrix given to warpAffine); mean/std_: HOST float[3];
+ *   out: DEVICE float32 NCHW [1 or 2,3,OH,OW]; flip != 0 also writes the mirrored twin as batch entry 1.
+ * cp_transform_dets_f32: lib/utils/post_process.py:8-19 + lib/utils/image.py:19-24 on the device: the 2 box corners
+ *   and J keypoints of dets[B,K,5+3J] through the per-image 2x3 double matrix trans[B][6], then / scale. */
+int cp_preprocess_u8_f32(const unsigned char* img, int H, int W, const float* M, float* out, int OH, int OW, const float* mean,
+                         const float* std_, int flip, void* stream);
+int cp_transform_dets_f32(const float* dets, float* out, const double* trans, int B, int K, int J, float scale, void* stream);
+
 /* ---- heat-map decode -------------------------------------------------------------------------
  * Replaces multi_pose_decode(heat, wh, kps, reg, hm_hp, hp_offset, K)
  *   lib/models/decode.py:235-308 (with _nms :10-16, _topk :99-115, _topk_channel :87-96,

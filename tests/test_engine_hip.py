@@ -131,3 +131,35 @@ def test_engine_determinism():
     b = eng(x)
     torch.cuda.synchronize()
     assert all(torch.equal(p, q) for p, q in zip(a, b))
+
+
+def test_device_preprocess_matches_host_restatement():
+    """cp_preprocess_u8_f32 (warp + normalise + HWC->CHW + mirrored twin) vs the numpy float restatement."""
+    from centerpose_amd import config, detector
+    cfg = config.get_cfg("res_50", TEST__FLIP_TEST=True)
+    det = detector.MultiPoseDetector(cfg)
+    img = (np.random.RandomState(1).rand(217, 333, 3) * 255).astype(np.uint8)
+    for scale in (1, 0.5):
+        det.device_preprocess = True
+        a, meta_a = det.pre_process(img, scale)
+        det.device_preprocess = False
+        b, meta_b = det.pre_process(img, scale)
+        assert a.is_cuda and not b.is_cuda and a.shape == b.shape == (2, 3, 512, 512)
+        assert np.allclose(a.cpu().numpy(), b.numpy(), atol=2e-4)
+        assert all(np.array_equal(np.asarray(meta_a[k]), np.asarray(meta_b[k])) for k in meta_a)
+
+
+def test_device_postprocess_matches_host():
+    from centerpose_amd import config, detector
+    cfg = config.get_cfg("res_50", TEST__FLIP_TEST=False)
+    det = detector.MultiPoseDetector(cfg)
+    dets = torch.from_numpy((np.random.RandomState(2).rand(1, 100, 56) * 128).astype(np.float32)).cuda()
+    meta = {"c": np.array([320., 240.], np.float32), "s": 640.0, "out_height": 128, "out_width": 128}
+    for scale in (1, 2, 0.75):
+        det.device_postprocess = True
+        a = det.post_process(dets, meta, scale)[1]
+        det.device_postprocess = False
+        b = det.post_process(dets, meta, scale)[1]
+        assert a.shape == b.shape == (100, 56)
+        assert np.allclose(a, b, rtol=0, atol=1e-4 * 128)
+        assert np.array_equal(a[:, 4], b[:, 4]) and np.array_equal(a[:, 39:], b[:, 39:])
