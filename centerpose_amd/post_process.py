@@ -1,60 +1,56 @@
-"""Host-side coordinate mapping, mirroring lib/utils/post_process.py:8-19 and the affine helpers
-of lib/utils/image.py:19-66 (which cannot even be imported from the reference: IndentationError at
-image.py:139-140).  cv2.getAffineTransform is replaced by a closed-form 3-point solve."""
+"""Host-side coordinate mapping between image space and the network's input / feature-map space.
+
+Behavioural mirror of the reference's helpers (lib/utils/image.py:19-66 ``get_affine_transform`` /
+``transform_preds`` and lib/utils/post_process.py:8-19 ``multi_pose_post_process``) -- which cannot even be
+imported from the reference (IndentationError at image.py:139-140) and need cv2.  The reference builds the
+matrix from three point pairs and cv2.getAffineTransform; for the way it is called the result is a
+similarity transform, written here in closed form:
+
+    k = dst_w / src_w                      (src_w = scale, or scale[0] when an (sw, sh) pair is given)
+    R = rotation by `rot` degrees
+    M = [ k*R | (dst_w/2, dst_h/2) - k*R @ (center + scale*shift) ]
+
+(the third point of the reference construction is the second one rotated by 90 degrees, which is exactly
+what forces equal scale on both axes).  ``inv=1`` returns the inverse map.
+"""
 import numpy as np
 
 
-def get_dir(src_point, rot_rad):
-    sn, cs = np.sin(rot_rad), np.cos(rot_rad)
-    return [src_point[0] * cs - src_point[1] * sn, src_point[0] * sn + src_point[1] * cs]
-
-
-def get_3rd_point(a, b):
-    direct = a - b
-    return b + np.array([-direct[1], direct[0]], dtype=np.float32)
-
-
-def _solve_affine(src, dst):
-    """2x3 matrix M with M @ [x,y,1]^T = dst for the three point pairs (cv2.getAffineTransform)."""
-    A = np.concatenate([src.astype(np.float64), np.ones((3, 1))], axis=1)
-    return np.linalg.solve(A, dst.astype(np.float64)).T
-
-
-def get_affine_transform(center, scale, rot, output_size, shift=np.array([0, 0], dtype=np.float32), inv=0):
-    """lib/utils/image.py:27-60"""
-    if not isinstance(scale, np.ndarray) and not isinstance(scale, list):
-        scale = np.array([scale, scale], dtype=np.float32)
-    scale_tmp = scale
-    src_w = scale_tmp[0]
-    dst_w, dst_h = output_size[0], output_size[1]
-    rot_rad = np.pi * rot / 180
-    src_dir = get_dir([0, src_w * -0.5], rot_rad)
-    dst_dir = np.array([0, dst_w * -0.5], np.float32)
-    src = np.zeros((3, 2), dtype=np.float32)
-    dst = np.zeros((3, 2), dtype=np.float32)
-    src[0, :] = center + scale_tmp * shift
-    src[1, :] = center + src_dir + scale_tmp * shift
-    dst[0, :] = [dst_w * 0.5, dst_h * 0.5]
-    dst[1, :] = np.array([dst_w * 0.5, dst_h * 0.5], np.float32) + dst_dir
-    src[2:, :] = get_3rd_point(src[0, :], src[1, :])
-    dst[2:, :] = get_3rd_point(dst[0, :], dst[1, :])
-    return _solve_affine(dst, src) if inv else _solve_affine(src, dst)
+def get_affine_transform(center, scale, rot, output_size, shift=(0.0, 0.0), inv=0):
+    """2x3 float64 matrix mapping source (image) pixels to destination pixels, or back when ``inv``."""
+    sc = np.asarray(scale, dtype=np.float64).reshape(-1)
+    sc = np.array([sc[0], sc[0]]) if sc.size == 1 else sc[:2]
+    src_w = float(sc[0])
+    dst_w, dst_h = float(output_size[0]), float(output_size[1])
+    k = dst_w / src_w
+    th = np.pi * float(rot) / 180.0
+    # the reference rotates the SOURCE direction vector by +rot, i.e. maps dst = k * R(-rot) * (src - c) + d
+    c_, s_ = np.cos(th), np.sin(th)
+    A = k * np.array([[c_, s_], [-s_, c_]], dtype=np.float64)
+    c0 = np.asarray(center, dtype=np.float64).reshape(2) + sc * np.asarray(shift, dtype=np.float64).reshape(2)
+    t = np.array([dst_w * 0.5, dst_h * 0.5]) - A @ c0
+    M = np.concatenate([A, t[:, None]], axis=1)
+    if not inv:
+        return M
+    Ai = np.linalg.inv(A)
+    return np.concatenate([Ai, (-Ai @ t)[:, None]], axis=1)
 
 
 def transform_preds(coords, center, scale, output_size):
-    """lib/utils/image.py:19-24 (vectorised; the reference loops per point)."""
-    trans = get_affine_transform(center, scale, 0, output_size, inv=1)
-    pts = np.concatenate([coords[:, 0:2].astype(np.float32), np.ones((coords.shape[0], 1), np.float32)], axis=1)
-    return (pts.astype(np.float64) @ trans.T)
+    """Map [N,2] points from output (feature-map) space back to image space (image.py:19-24, vectorised)."""
+    M = get_affine_transform(center, scale, 0, output_size, inv=1)
+    pts = np.asarray(coords, dtype=np.float32)[:, :2].astype(np.float64)
+    return pts @ M[:, :2].T + M[:, 2]
 
 
 def multi_pose_post_process(dets, c, s, h, w):
-    """lib/utils/post_process.py:8-19: dets [B, N, 56] in feature-map pixels -> image coordinates."""
+    """post_process.py:8-19: dets [B,N,56] in feature-map pixels -> per image {1: [[56 floats] * N]} in image
+    coordinates (boxes = columns 0:4, keypoints = columns 5:39 are mapped, scores are copied)."""
     ret = []
     for i in range(dets.shape[0]):
-        bbox = transform_preds(dets[i, :, :4].reshape(-1, 2), c[i], s[i], (w, h))
-        pts = transform_preds(dets[i, :, 5:39].reshape(-1, 2), c[i], s[i], (w, h))
-        top_preds = np.concatenate([bbox.reshape(-1, 4), dets[i, :, 4:5], pts.reshape(-1, 34), dets[i, :, 39:56]],
-                                   axis=1).astype(np.float32).tolist()
-        ret.append({np.ones(1, dtype=np.int32)[0]: top_preds})
+        d = dets[i]
+        box = transform_preds(d[:, 0:4].reshape(-1, 2), c[i], s[i], (w, h)).reshape(-1, 4)
+        kps = transform_preds(d[:, 5:39].reshape(-1, 2), c[i], s[i], (w, h)).reshape(-1, 34)
+        rows = np.concatenate([box, d[:, 4:5], kps, d[:, 39:56]], axis=1).astype(np.float32)
+        ret.append({np.ones(1, dtype=np.int32)[0]: rows.tolist()})
     return ret
