@@ -68,6 +68,7 @@ def main():
     rank, world, local = cpd.init_from_env()
     assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    local = local % torch.cuda.device_count()     # (lets a 1-GPU box smoke-test the N>1 control flow over gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -21,9 +21,9 @@ def init_from_env(backend=None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("CP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
     return rank, world, local
 
@@ -42,9 +42,10 @@ def gather_dets(dets, world=None):
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return dets
     world = dist.get_world_size()
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dets.device) for _ in range(world)]
-    mine = torch.tensor([dets.shape[0]], dtype=torch.int64, device=dets.device)
     backend = dist.get_backend()
+    sdev = dets.device if backend == "nccl" else torch.device("cpu")
+    sizes = [torch.zeros(1, dtype=torch.int64, device=sdev) for _ in range(world)]
+    mine = torch.tensor([dets.shape[0]], dtype=torch.int64, device=sdev)
     if getattr(gather_dets, "_equal", None) is None:
         dist.all_gather(sizes, mine)
         gather_dets._sizes = [int(s.item()) for s in sizes]
@@ -53,6 +54,8 @@ def gather_dets(dets, world=None):
         out = torch.empty((world * dets.shape[0],) + tuple(dets.shape[1:]), dtype=dets.dtype, device=dets.device)
         dist.all_gather_into_tensor(out, dets.contiguous())
         return out
+    if backend == "gloo" and dets.is_cuda:       # gloo has no CUDA all_gather: stage through the host (tests only)
+        return gather_dets(dets.cpu()).to(dets.device)
     mx = max(gather_dets._sizes)
     pad = dets
     if dets.shape[0] < mx:

@@ -18,6 +18,12 @@ CASES = {  # name: (B, H, W, Cin, Cout, k, stride, pad, kind)
     "l0": (16, 512, 512, 16, 16, 3, 1, 1, "conv"),
     "l1": (16, 512, 512, 16, 32, 3, 2, 1, "conv"),
     "stem": (16, 512, 512, 3, 16, 7, 1, 3, "stem"),
+    "p64_256": (16, 128, 128, 64, 256, 1, 1, 0, "conv"),
+    "p256_64": (16, 128, 128, 256, 64, 1, 1, 0, "conv"),
+    "p512_128": (16, 64, 64, 512, 128, 1, 1, 0, "conv"),
+    "p1024_256": (16, 32, 32, 1024, 256, 1, 1, 0, "conv"),
+    "p2048_512": (16, 16, 16, 2048, 512, 1, 1, 0, "conv"),
+    "s2_128": (16, 128, 128, 128, 128, 3, 2, 1, "conv"),
     "d64_128": (16, 128, 128, 64, 64, 3, 1, 1, "dcn"),
     "d128_64": (16, 64, 64, 128, 128, 3, 1, 1, "dcn"),
     "d512_16": (16, 16, 16, 512, 256, 3, 1, 1, "dcn"),
