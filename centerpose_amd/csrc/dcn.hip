@@ -202,6 +202,7 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
         case 128032: rc = launch_dcn<128, 32, 4, 1, 32>(a, s); break;
         case 128064: rc = launch_dcn<128, 64, 2, 2, 32>(a, s); break;
         case 64064: rc = launch_dcn<64, 64, 2, 2, 32>(a, s); break;
+        case 128128: rc = launch_dcn<128, 128, 2, 2, 32>(a, s); break;
         default: CP_CHECK_ARG(false, "dcn_v2: unsupported tile %d (ldw=%d)", tile, d->ldw);
     }
     if (rc) return rc;

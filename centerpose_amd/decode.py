@@ -22,6 +22,13 @@ def multi_pose_decode(heat, wh, kps, reg=None, hm_hp=None, hp_offset=None, K=100
     reg = reg.contiguous() if reg is not None else None
     hp_offset = hp_offset.contiguous() if hp_offset is not None else None
     dev = heat.device
+    if B == 0:        # empty batch: the reference's torch ops return an empty [0,K,56] tensor
+        _lib.ptr(heat)   # still refuse CPU tensors
+        dets = torch.empty((0, K, 5 + 3 * J), dtype=torch.float32, device=dev)
+        if return_indices:
+            return (dets, torch.empty((0, K), dtype=torch.int32, device=dev),
+                    torch.empty((0, J, K), dtype=torch.int32, device=dev), torch.empty((0, 1 + J, K), device=dev))
+        return dets
     dets = torch.empty((B, K, 5 + 3 * J), dtype=torch.float32, device=dev)
     ws_scores = torch.empty((B, 1 + J, K), dtype=torch.float32, device=dev)
     ws_inds = torch.empty((B, 1 + J, K), dtype=torch.int32, device=dev)

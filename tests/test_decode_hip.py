@@ -83,3 +83,24 @@ def test_hip_decode_error_behaviour():
         cp.multi_pose_decode(t["hm"].cpu(), t["wh"].cpu(), t["hps"].cpu(), None, t["hm_hp"].cpu(), None, K=10)
     with pytest.raises(CenterposeHipError):   # K larger than the map
         cp.multi_pose_decode(t["hm"], t["wh"], t["hps"], t["reg"], t["hm_hp"], None, K=257)
+
+
+@pytest.mark.parametrize("B,H,W,J,K", [(1, 16, 16, 17, 1), (2, 16, 16, 3, 256), (1, 128, 256, 17, 100), (3, 8, 200, 2, 7)])
+def test_hip_decode_edge_shapes(B, H, W, J, K):
+    """K = 1, K = 256 (== the whole 16x16 map), the largest LDS-resident map (128x256 = 32768 keys), thin maps."""
+    inp = cases.decode_random(1000 + K, B=B, H=H, W=W, J=J)
+    ref, aux = decode_np.multi_pose_decode(inp["hm"], inp["wh"], inp["hps"], inp["reg"], inp["hm_hp"],
+                                           inp["hp_offset"], K=K, return_aux=True)
+    dets, inds, hm_inds = _hip(inp, K, True, True)
+    assert np.array_equal(inds, aux["inds"]) and np.array_equal(hm_inds, aux["hm_inds"])
+    assert np.array_equal(dets, ref)
+
+
+def test_hip_decode_empty_batch_and_limits():
+    import centerpose_amd as cp
+    from centerpose_amd._lib import CenterposeHipError
+    z = lambda *s: torch.zeros(*s, device="cuda")
+    dets = cp.multi_pose_decode(z(0, 1, 16, 16), z(0, 2, 16, 16), z(0, 34, 16, 16), None, z(0, 17, 16, 16), None, K=10)
+    assert tuple(dets.shape) == (0, 10, 56)
+    with pytest.raises(CenterposeHipError):     # 33k keys do not fit the LDS-resident plane
+        cp.multi_pose_decode(z(1, 1, 129, 256), z(1, 2, 129, 256), z(1, 34, 129, 256), None, z(1, 17, 129, 256), None, K=10)
