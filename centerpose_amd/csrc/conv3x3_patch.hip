@@ -96,13 +96,13 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(const Conv
     float* bdst = Bs + (b_t0 * BN + b_n) * IG_LDK + b_q * 4;
     float4 ar0, ar1, ar2, b0, b1, b2, b3, b4, b5, b6, b7, b8;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define P3_LB(s, c0) ((TPS * (s) + b_t0 < 9) ? *reinterpret_cast<const float4*>(wrow + (TPS * (s) + b_t0) * C + (c0)) : zero4)
+#define P3_LB(s, c0) ((TPS * (s) + b_t0 < 9) ? ig_ldg4(wrow + (TPS * (s) + b_t0) * C + (c0)) : zero4)
 #define P3_SB(s, v) if (TPS * (s) + b_t0 < 9) *reinterpret_cast<float4*>(bdst + TPS * (s) * BN * IG_LDK) = (v)
 #define P3_LOAD(c0)                                                                                          \
     {                                                                                                        \
-        const float4 v0 = *reinterpret_cast<const float4*>(x + (a_goff0 >= 0 ? a_goff0 + (c0) : 0));        \
-        const float4 v1 = *reinterpret_cast<const float4*>(x + (a_goff1 >= 0 ? a_goff1 + (c0) : 0));        \
-        const float4 v2 = *reinterpret_cast<const float4*>(x + (a_goff2 >= 0 ? a_goff2 + (c0) : 0));        \
+        const float4 v0 = ig_ldg4(x + (a_goff0 >= 0 ? a_goff0 + (c0) : 0));                                  \
+        const float4 v1 = ig_ldg4(x + (a_goff1 >= 0 ? a_goff1 + (c0) : 0));                                  \
+        const float4 v2 = ig_ldg4(x + (a_goff2 >= 0 ? a_goff2 + (c0) : 0));                                  \
         ar0 = a_goff0 >= 0 ? v0 : zero4;                                                                     \
         ar1 = a_goff1 >= 0 ? v1 : zero4;                                                                     \
         ar2 = a_goff2 >= 0 ? v2 : zero4;                                                                     \
@@ -147,6 +147,9 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(const Conv
         for (int t = 0; t < 9; ++t) {
             const int cb = t & 1;
             if (t + 1 < 9) { P3_FRAG(cb ^ 1, t + 1) }
+            // pin the order: tap t+1's LDS reads are ISSUED before tap t's MFMAs (otherwise the scheduler sinks
+            // them next to their use, re-using one register set, and every tap waits a full LDS round trip)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int h = 0; h < NH; ++h)
 #pragma unroll

@@ -61,6 +61,15 @@ struct ConvArgs {
 // conv3x3_patch.hip: returns -1 when the shape is not eligible, else 0 / error code
 int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s, int variant = 0);
 
+// 16-byte load through an explicit GLOBAL address-space pointer.  A generic (flat) load also increments
+// lgkmcnt, so every `s_waitcnt lgkmcnt` guarding an LDS fragment read would wait for the prefetch as well.
+typedef float ig_v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ig_ldg4(const float* p)
+{
+    const ig_v4f v = *(const __attribute__((address_space(1))) ig_v4f*)(p);
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+
 // XCD-aware, bijective remap of the linear block id: blocks that are consecutive in the
 // remapped order (and share the same activation rows) land on the same XCD / L2.
 __device__ __forceinline__ int ig_xcd_remap(int id, int n)
