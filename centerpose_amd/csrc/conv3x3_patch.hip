@@ -95,26 +95,24 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(const Conv
     const float* wrow = a.w + (size_t)(n0 + b_n) * a.K + b_q * 4;
     float* bdst = Bs + (b_t0 * BN + b_n) * IG_LDK + b_q * 4;
     float4 ar0, ar1, ar2, b0, b1, b2, b3, b4, b5, b6, b7, b8;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-#define P3_LB(s, c0) ((TPS * (s) + b_t0 < 9) ? ig_ldg4(wrow + (TPS * (s) + b_t0) * C + (c0)) : zero4)
+#define P3_LB(s, c0) ig_ldg4(wrow + ((TPS * (s) + b_t0 < 9) ? (TPS * (s) + b_t0) : 8) * C + (c0))   /* unconditional, tap clamped; P3_SB guards the store */
 #define P3_SB(s, v) if (TPS * (s) + b_t0 < 9) *reinterpret_cast<float4*>(bdst + TPS * (s) * BN * IG_LDK) = (v)
 #define P3_LOAD(c0)                                                                                          \
     {                                                                                                        \
-        const float4 v0 = ig_ldg4(x + (a_goff0 >= 0 ? a_goff0 + (c0) : 0));                                  \
-        const float4 v1 = ig_ldg4(x + (a_goff1 >= 0 ? a_goff1 + (c0) : 0));                                  \
-        const float4 v2 = ig_ldg4(x + (a_goff2 >= 0 ? a_goff2 + (c0) : 0));                                  \
-        ar0 = a_goff0 >= 0 ? v0 : zero4;                                                                     \
-        ar1 = a_goff1 >= 0 ? v1 : zero4;                                                                     \
-        ar2 = a_goff2 >= 0 ? v2 : zero4;                                                                     \
+        /* raw loads only: zeroing of out-of-image pixels happens at store time -- a select here would make   \
+           the wave wait for the prefetch (s_waitcnt vmcnt) before the chunk's MFMAs even start */           \
+        ar0 = ig_ldg4(x + (a_goff0 >= 0 ? a_goff0 + (c0) : 0));                                              \
+        ar1 = ig_ldg4(x + (a_goff1 >= 0 ? a_goff1 + (c0) : 0));                                              \
+        ar2 = ig_ldg4(x + (a_goff2 >= 0 ? a_goff2 + (c0) : 0));                                              \
         b0 = P3_LB(0, c0); b1 = P3_LB(1, c0); b2 = P3_LB(2, c0);                                             \
         if (NBS > 3) { b3 = P3_LB(3, c0); b4 = P3_LB(4, c0); }                                               \
         if (NBS > 5) { b5 = P3_LB(5, c0); b6 = P3_LB(6, c0); b7 = P3_LB(7, c0); b8 = P3_LB(8, c0); }         \
     }
 #define P3_STORE(patch)                                                                                      \
     {                                                                                                        \
-        if (a_lds0 >= 0) *reinterpret_cast<float4*>((patch) + a_lds0) = ar0;                                \
-        if (a_lds1 >= 0) *reinterpret_cast<float4*>((patch) + a_lds1) = ar1;                                \
-        if (a_lds2 >= 0) *reinterpret_cast<float4*>((patch) + a_lds2) = ar2;                                \
+        if (a_lds0 >= 0) *reinterpret_cast<float4*>((patch) + a_lds0) = a_goff0 >= 0 ? ar0 : make_float4(0.f, 0.f, 0.f, 0.f);         \
+        if (a_lds1 >= 0) *reinterpret_cast<float4*>((patch) + a_lds1) = a_goff1 >= 0 ? ar1 : make_float4(0.f, 0.f, 0.f, 0.f);         \
+        if (a_lds2 >= 0) *reinterpret_cast<float4*>((patch) + a_lds2) = a_goff2 >= 0 ? ar2 : make_float4(0.f, 0.f, 0.f, 0.f);         \
         P3_SB(0, b0); P3_SB(1, b1); P3_SB(2, b2);                                                            \
         if (NBS > 3) { P3_SB(3, b3); P3_SB(4, b4); }                                                         \
         if (NBS > 5) { P3_SB(5, b5); P3_SB(6, b6); P3_SB(7, b7); P3_SB(8, b8); }                             \

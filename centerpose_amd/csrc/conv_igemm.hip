@@ -59,6 +59,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
             } else { ps[s].boff = -1; ps[s].iy0 = 0; ps[s].ix0 = 0; }
         }
         float4 ar[T::A_SLOTS];
+        bool aok[T::A_SLOTS];
         // k-walk state (wave-uniform): tap (ky,kx), source index, channel offset inside the source
         int ky = 0, kx = 0, si = 0, cl = 0;
 
@@ -71,8 +72,8 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
                 const bool ok = ps[s].boff >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
                 // branch-free: out-of-range taps read the (always valid) tensor base and are zeroed
                 const size_t off = ok ? (size_t)(ps[s].boff + iy * a.W + ix) * ld + cl + q * 4 : 0;
-                const float4 v = *reinterpret_cast<const float4*>(sp + off);
-                ar[s] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+                ar[s] = ig_ldg4(sp + off);            // raw; zeroed at store time (a select here would wait on vmcnt)
+                aok[s] = ok;
             }
         };
         auto advance = [&]() __attribute__((always_inline)) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
 #pragma unroll
             for (int s = 0; s < T::A_SLOTS; ++s) {
                 const int pl = (tid >> 2) + s * 64;
-                *reinterpret_cast<float4*>(As + pl * IG_LDK + q * 4) = ar[s];
+                *reinterpret_cast<float4*>(As + pl * IG_LDK + q * 4) = aok[s] ? ar[s] : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
 
