@@ -63,9 +63,12 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         // k-walk state (wave-uniform): tap (ky,kx), source index, channel offset inside the source
         int ky = 0, kx = 0, si = 0, cl = 0;
 
+        // current source (pointer / pixel stride / channels) lives in registers and is re-read from the
+        // kernel arguments only when the k-walk crosses into the next concatenated source: indexing
+        // a.src[si] in the loop costs 3 dependent scalar loads + s_waitcnt lgkmcnt(0) per k-step
+        const float* sp = a.src[0];
+        int ld = a.srcLd[0], sC = a.srcC[0];
         auto load_a = [&]() __attribute__((always_inline)) {
-            const float* sp = a.src[si];
-            const int ld = a.srcLd[si];
 #pragma unroll
             for (int s = 0; s < T::A_SLOTS; ++s) {
                 const int iy = ps[s].iy0 + ky, ix = ps[s].ix0 + kx;
@@ -78,7 +81,11 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         };
         auto advance = [&]() __attribute__((always_inline)) {
             cl += IG_BK;
-            if (cl >= a.srcC[si]) { cl = 0; if (++si >= a.nsrc) { si = 0; if (++kx >= a.kw) { kx = 0; ++ky; } } }
+            if (cl >= sC) {
+                cl = 0;
+                if (++si >= a.nsrc) { si = 0; if (++kx >= a.kw) { kx = 0; ++ky; } }
+                if (a.nsrc > 1) { sp = a.src[si]; ld = a.srcLd[si]; sC = a.srcC[si]; }
+            }
         };
         auto store_a = [&](float* As) __attribute__((always_inline)) {
 #pragma unroll
@@ -98,6 +105,9 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
             const bool more = ks + 1 < nk;
             if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
             ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc);
+            // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
+            // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
+            __builtin_amdgcn_sched_barrier(0);
             if (more) {
                 store_a(As0 + (cur ^ 1) * T::A_FLOATS);
                 ig_store_b<T>(Bs0 + (cur ^ 1) * T::B_FLOATS, tid, br);
@@ -148,6 +158,9 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
             const bool more = ks + 1 < nk;
             if (more) { load_a((ks + 1) * IG_BK); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
             ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc);
+            // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
+            // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
+            __builtin_amdgcn_sched_barrier(0);
             if (more) {
                 store_a(As0 + (cur ^ 1) * T::A_FLOATS);
                 ig_store_b<T>(Bs0 + (cur ^ 1) * T::B_FLOATS, tid, br);
