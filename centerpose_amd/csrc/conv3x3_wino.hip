@@ -1,0 +1,373 @@
+// 3x3 / stride 1 / pad 1 convolution as a fused Winograd F(2x2,3x3) on the fp32 matrix cores (gfx950).
+//
+// 3x3/s1 layers are ~75 % of the network's FLOPs (DLA base blocks, DCN offset convs, the six head
+// convs; pose_dla_dcn.py:29-57, keypoint.py:14-42).  F(2x2,3x3) computes a 2x2 output tile from a 4x4
+// input tile with 16 multiplies per (cin,cout) instead of 36:
+//     Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A         (Lavin & Gray; B, G, A have entries 0, +-1, +-1/2)
+// i.e. 16 independent GEMMs  M[xi][nu][tile][n] = sum_c V[xi][nu][tile][c] * U[xi][nu][n][c].
+// Everything is fused in one kernel; nothing of the Winograd domain touches HBM:
+//   * block = 8x16 output pixels = 4x8 Winograd tiles = ONE 32-row MFMA tile, times 32*NT output channels;
+//   * wave xi (0..3) owns transform row xi: the four frequencies (xi, nu=0..3).  Row xi of B^T has two
+//     non-zeros, so the wave needs only two of the four rows of every 4x4 input tile;
+//   * the raw (8+2)x(16+2) input patch is staged in LDS 16 channels at a time (double buffered, one
+//     barrier per stage).  A lane (tile m, k-half h) reads 8 ds_read_b128 (2 rows x 4 cols x 4 channels),
+//     forms V with 32 VALU adds and feeds it STRAIGHT into the MFMA A operand - V never exists in memory;
+//   * U (transformed weights, cp_winograd_pack_f32) is wave-private (each wave has its own frequencies),
+//     so its B fragments go global -> registers as coalesced 1 KiB wave loads, prefetched one 8-channel
+//     chunk ahead; no LDS, no barrier;
+//   * per 8-channel chunk and wave: 8 ds_read_b128 + 16 packed VALU + 4*NT global loads feed 16*NT
+//     v_mfma_f32_32x32x2f32 (64 cycles each).  Measured on MI355X (tools/micro/wino_loop.hip): every VALU
+//     instruction costs ~4 cycles of matrix-pipe time (no co-issue, same or other wave), so the transform and
+//     the epilogue use v_pk_{add,fma}_f32 and block-index math is scalar (host-side magic division);
+//   * epilogue: the nu-sum of A is done in registers, the xi-sum across the four waves through LDS, then
+//     scale/shift (folded BN) + residual + activation and float4 NHWC stores.
+// Arithmetic is fp32 throughout; the result differs from the direct convolution by ordinary fp32
+// rounding (~1e-6 relative, measured in tests/test_conv_hip.py), far inside the path's 1e-3 bar.
+#include "igemm.h"
+
+#define WG_TW 16
+#define WG_PW (WG_TW + 2)
+#define WG_PWP 20                                  // padded patch row, in float4 slots (even: see the swizzle)
+#define WG_LDR 36                                  // reduction-buffer row pitch (floats)
+#define WG_RED (8 * 32 * WG_LDR)                   // [xi][b][tile][n] floats
+
+typedef float wg_v2 __attribute__((ext_vector_type(2)));
+typedef float wg_v4 __attribute__((ext_vector_type(4)));
+
+template <int MT, int KS> struct WgGeo {
+    static constexpr int TH = 8 * MT, PH = TH + 2;
+    static constexpr int CGS = KS / 4;                   // 4-channel groups per stage
+    static constexpr int CG = PH * WG_PWP * 4;          // floats per 4-channel group plane
+    static constexpr int STAGE = CGS * CG;               // floats per stage buffer
+    static constexpr int F4 = PH * WG_PW * CGS;          // float4 per stage
+    static constexpr int SLOTS = (F4 + IG_THREADS - 1) / IG_THREADS;
+    static constexpr int SMEM_FLOATS = 2 * STAGE > WG_RED ? 2 * STAGE : WG_RED;
+};
+
+// launch geometry; block-index decomposition uses host-made magic numbers: q = mulhi(n, ceil(2^32/d)) is exact
+// for n*d < 2^32 (checked on the host), and stays on the scalar unit
+struct WgGrid {
+    int tilesX, tilesY, ntb;
+    unsigned mNtb, mTx, mTy;
+};
+__device__ __forceinline__ int wg_div(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+
+__device__ __forceinline__ wg_v4 wg_lds4(const float* p) { return *reinterpret_cast<const wg_v4*>(p); }
+
+// MT = 32-tile M sets per block (block = 8*MT x 16 output pixels), NT = 32-channel N tiles per block,
+// KS = channels per LDS stage, NB = U-fragment register sets (prefetch distance NB-1 chunks).
+// The U fragment of a chunk is used by MT MFMAs, the V fragment by NT: U traffic per flop ~ 1/MT,
+// LDS reads + transform VALU per flop ~ 1/NT.
+template <int MT, int NT, int KS, int NB>
+__global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : 2) void conv3x3_wino_kernel(const ConvArgs a, const WgGrid gd)
+{
+    using Geo = WgGeo<MT, KS>;
+    constexpr int CPS = KS / 8, U = CPS * MT;          // chunks / units per stage
+    static_assert(CPS % NB == 0 && NB >= 2, "static U-fragment register rotation");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    const int NTILES = (a.Cout + 31) >> 5;             // 32-channel tiles in the packed U
+    int t_ = ig_xcd_remap(blockIdx.x, gridDim.x), q_;
+    q_ = wg_div(t_, gd.ntb, gd.mNtb); const int nb = t_ - q_ * gd.ntb; t_ = q_;
+    q_ = wg_div(t_, gd.tilesX, gd.mTx); const int tx = t_ - q_ * gd.tilesX; t_ = q_;
+    q_ = wg_div(t_, gd.tilesY, gd.mTy); const int ty = t_ - q_ * gd.tilesY;
+    const int b = q_;
+    const int y0 = ty * Geo::TH, x0 = tx * WG_TW;
+    const int C = a.srcC[0], ld = a.srcLd[0];
+    const int KC = C >> 3;                             // 8-channel chunks
+    const float* __restrict__ x = a.src[0];
+    // whole halo patch inside the image: no zero-select at LDS-store time (block-uniform)
+    const bool interior = y0 >= 1 && y0 + Geo::TH + 1 <= a.H && x0 >= 1 && x0 + WG_TW + 1 <= a.W;
+
+    // ---- staging slots (fixed per thread): patch pixel pp, channel group q.  LDS layout [q][py][px ^ f(py)][4],
+    // f(py) = (py >> 1) & 1: the 16 lanes of a ds_read_b128 group are 8 tile columns (float4 slots 2*txx + j,
+    // all of one parity) x 2 tile rows (2 patch rows apart = 40 slots, even); flipping the slot parity on
+    // every other tile row makes the 16 slots distinct mod 16 -> conflict-free fragment reads.
+    int go[Geo::SLOTS], lo[Geo::SLOTS];
+    bool ok[Geo::SLOTS];
+#pragma unroll
+    for (int s = 0; s < Geo::SLOTS; ++s) {
+        const int idx = tid + s * IG_THREADS;
+        const int pp = idx / Geo::CGS, q = idx % Geo::CGS;
+        const int py = pp / WG_PW, px = pp - py * WG_PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool inl = idx < Geo::F4;
+        ok[s] = inl && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        go[s] = ok[s] ? ((b * a.H + gy) * a.W + gx) * ld + q * 4 : 0;
+        lo[s] = inl ? ((q * Geo::PH + py) * WG_PWP + (px ^ ((py >> 1) & 1))) * 4 : -1;
+    }
+    float4 rg[Geo::SLOTS];
+    auto stage_load = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < Geo::SLOTS; ++s) rg[s] = ig_ldg4(x + go[s] + c0);     // raw; zeroed at store time
+    };
+    auto stage_store = [&](float* buf) __attribute__((always_inline)) {
+        if (interior) {
+#pragma unroll
+            for (int s = 0; s < Geo::SLOTS; ++s)
+                if (lo[s] >= 0) *reinterpret_cast<float4*>(buf + lo[s]) = rg[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < Geo::SLOTS; ++s)
+                if (lo[s] >= 0) {
+                    float4 v = rg[s];
+                    if (!ok[s]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(buf + lo[s]) = v;
+                }
+        }
+    };
+
+    // ---- wave's transform row: t[j] = d[rA][j] + sg * d[rB][j]
+    const int rA = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+    const int rB = xi == 2 ? 1 : (xi == 3 ? 3 : 2);
+    const float sg1 = xi == 1 ? 1.f : -1.f;
+    const wg_v2 sg = {sg1, sg1};
+    const int tyy = m >> 3, txx = m & 7;
+    const int fA = (tyy + (rA >> 1)) & 1, fB = (tyy + (rB >> 1)) & 1;      // slot-parity flip of the lane's rows
+    const int baseA = ((2 * tyy + rA) * WG_PWP + 2 * txx) * 4 + h * Geo::CG;
+    const int baseB = ((2 * tyy + rB) * WG_PWP + 2 * txx) * 4 + h * Geo::CG;
+    // column j lives in slot 2*txx + (j ^ f): even j -> +f, odd j -> -f
+    const int offAe = baseA + fA * 4, offAo = baseA - fA * 4, offBe = baseB + fB * 4, offBo = baseB - fB * 4;
+
+    // ---- U fragments: [xi][ntile][kc][nu][lane][4]
+    const float* ub[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        int tile = nb * NT + nt;
+        if (tile >= NTILES) tile = NTILES - 1;          // ragged last block: compute a duplicate, never stored
+        ub[nt] = a.w + ((size_t)(xi * NTILES + tile) * KC) * 1024 + lane * 4;
+    }
+    float4 bq[NB][NT][4];
+    auto load_u = [&](int kc, float4 (&dst)[NT][4]) __attribute__((always_inline)) {
+        const int kk = kc < KC ? kc : KC - 1;              // clamped: prefetches past the end re-read the last chunk
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) dst[nt][nu] = ig_ldg4(ub[nt] + (size_t)kk * 1024 + nu * 256);
+    };
+
+    f32x16 acc[MT][NT][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][nu][r] = 0.f;
+
+    stage_load(0);
+#pragma unroll
+    for (int s = 0; s < NB - 1; ++s) load_u(s, bq[s]);
+    stage_store(smem);
+    __syncthreads();
+
+    const int nstage = C / KS;
+#pragma unroll 1
+    for (int st = 0; st < nstage; ++st) {
+        const float* buf = smem + (st & 1) * Geo::STAGE;
+        const bool more = st + 1 < nstage;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ch = u / MT, mt = u % MT;
+            if (mt == 0) load_u(st * CPS + ch + NB - 1, bq[(ch + NB - 1) % NB]);
+            // vmcnt retires in order: the next stage's patch loads (HBM latency) must be YOUNGER than every U
+            // fragment load that is consumed inside this stage, or each such wait would also wait for the patch
+            if (u == (NB - 2) * MT && more) stage_load((st + 1) * KS);
+            // V = B^T d B for the wave's row xi: packed fp32 math, 16 VALU instructions per unit
+            const float* pc = buf + ch * 2 * Geo::CG + mt * (8 * WG_PWP * 4);       // tile set mt: 4 tile rows down
+            wg_v2 tl[4], th[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const wg_v4 da = wg_lds4(pc + ((j & 1) ? offAo : offAe) + j * 4);
+                const wg_v4 db = wg_lds4(pc + ((j & 1) ? offBo : offBe) + j * 4);
+                tl[j] = __builtin_elementwise_fma(sg, db.xy, da.xy);
+                th[j] = __builtin_elementwise_fma(sg, db.zw, da.zw);
+            }
+            wg_v2 vl[4], vh[4];
+            vl[0] = tl[0] - tl[2]; vh[0] = th[0] - th[2];
+            vl[1] = tl[1] + tl[2]; vh[1] = th[1] + th[2];
+            vl[2] = tl[2] - tl[1]; vh[2] = th[2] - th[1];
+            vl[3] = tl[1] - tl[3]; vh[3] = th[1] - th[3];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 bb = bq[ch % NB][nt][nu];
+                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[nu].x, bb.x, acc[mt][nt][nu], 0, 0, 0);
+                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[nu].y, bb.y, acc[mt][nt][nu], 0, 0, 0);
+                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[nu].x, bb.z, acc[mt][nt][nu], 0, 0, 0);
+                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[nu].y, bb.w, acc[mt][nt][nu], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) stage_store(smem + ((st + 1) & 1) * Geo::STAGE);
+        __syncthreads();
+    }
+
+    // ---- epilogue: Y = A^T M A.  nu-sum in registers, xi-sum across waves through LDS.
+    const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
+    const bool vec_ok = (a.outLd & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
+                        (!a.res || ((a.resLd & 3) == 0 && (((size_t)a.res) & 15) == 0));
+    float* red = smem;
+    // fixed per thread: reduction-buffer write base and the two output items (tile mi, column bb, 4 channels n4)
+    const int wbase = (xi * 64 + 4 * h) * WG_LDR + m;       // row (xi*2+b)*32 + ig_row(r): + b*32*LDR + ((r&3)+8*(r>>2))*LDR
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (mt + nt) __syncthreads();
+        {
+            const f32x16 s0 = acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2];
+            const f32x16 s1 = acc[mt][nt][1] - acc[mt][nt][2] - acc[mt][nt][3];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                red[wbase + ((r & 3) + 8 * (r >> 2)) * WG_LDR] = s0[r];
+                red[wbase + (32 + (r & 3) + 8 * (r >> 2)) * WG_LDR] = s1[r];
+            }
+        }
+        __syncthreads();
+        const int tile = nb * NT + nt;
+        if (tile >= NTILES) continue;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tid + it * IG_THREADS;
+            const int n4 = item & 7, bb = (item >> 3) & 1, mi = item >> 4;
+            const int n = tile * 32 + n4 * 4;
+            const int ox = x0 + 2 * (mi & 7) + bb;
+            if (ox >= a.W || n >= a.Cout) continue;
+            const float* rp = red + (bb * 32 + mi) * WG_LDR + n4 * 4;
+            const wg_v4 q0 = wg_lds4(rp), q1 = wg_lds4(rp + 64 * WG_LDR), q2 = wg_lds4(rp + 128 * WG_LDR),
+                        q3 = wg_lds4(rp + 192 * WG_LDR);
+            wg_v4 yv[2];
+            yv[0] = (q0 + q1) + q2;
+            yv[1] = (q1 - q2) - q3;
+            const int oy0 = y0 + mt * 8 + 2 * (mi >> 3);
+            const size_t opix0 = ((size_t)b * a.H + oy0) * a.W + ox;
+            if (vec_ok && n + 3 < a.Cout) {
+                const wg_v4 sc = *reinterpret_cast<const wg_v4*>(a.scale + n);
+                const wg_v4 sh = *reinterpret_cast<const wg_v4*>(a.shift + n);
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa) {
+                    if (oy0 + aa >= a.H) continue;
+                    const size_t opix = opix0 + (size_t)aa * a.W;
+                    wg_v4 v = __builtin_elementwise_fma(yv[aa], sc, sh);
+                    if (a.res) v += *reinterpret_cast<const wg_v4*>(a.res + opix * a.resLd + n);
+                    if (relu) v = __builtin_elementwise_max(v, (wg_v4){0.f, 0.f, 0.f, 0.f});
+                    else if (sigm) {
+                        v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
+                        v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
+                    }
+                    *reinterpret_cast<wg_v4*>(a.out + opix * a.outLd + n) = v;
+                }
+            } else {
+#pragma unroll
+                for (int aa = 0; aa < 2; ++aa) {
+                    if (oy0 + aa >= a.H) continue;
+                    const size_t opix = opix0 + (size_t)aa * a.W;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (n + k >= a.Cout) break;
+                        float w_ = yv[aa][k] * a.scale[n + k] + a.shift[n + k];
+                        if (a.res) w_ += a.res[opix * a.resLd + n + k];
+                        if (relu) w_ = fmaxf(w_, 0.f);
+                        else if (sigm) w_ = 1.0f / (1.0f + __expf(-w_));
+                        a.out[opix * a.outLd + n + k] = w_;
+                    }
+                }
+            }
+        }
+    }
+}
+
+static unsigned wg_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+
+template <int MT, int NT, int KS, int NB>
+static int launch_wino(const ConvArgs& a, hipStream_t s)
+{
+    auto kern = conv3x3_wino_kernel<MT, NT, KS, NB>;
+    using Geo = WgGeo<MT, KS>;
+    const int smem = Geo::SMEM_FLOATS * 4;
+    WgGrid gd;
+    gd.tilesX = cp_cdiv(a.W, WG_TW); gd.tilesY = cp_cdiv(a.H, Geo::TH);
+    const int ntiles = (a.Cout + 31) / 32;
+    gd.ntb = (ntiles + NT - 1) / NT;
+    gd.mNtb = wg_magic(gd.ntb); gd.mTx = wg_magic(gd.tilesX); gd.mTy = wg_magic(gd.tilesY);
+    const long long grid = (long long)a.B * gd.tilesX * gd.tilesY * gd.ntb;
+    const long long dmax = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
+    if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd: grid %lld too large", grid); return 1; }
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
+    return 0;
+}
+
+// a.w = Winograd-domain weights from cp_winograd_pack_f32.  Returns -1 when the shape is not eligible.
+int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
+{
+    const bool ok = a.nsrc == 1 && a.kh == 3 && a.kw == 3 && a.sy == 1 && a.sx == 1 && a.py == 1 && a.px == 1 &&
+                    !a.outNCHW && a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Ho == a.H && a.Wo == a.W &&
+                    a.OH == a.H && a.OW == a.W && a.srcC[0] % 16 == 0 && a.srcLd[0] % 4 == 0 &&
+                    (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
+    if (!ok) return -1;
+    const int ntiles = (a.Cout + 31) / 32;
+    // variant = MT*10 + NT (tuning / tests); 0 = auto.  Measured on MI355X (tools/bench_conv.py, B = 16): the 16x16-pixel
+    // block (MT = 2) wins while it still gives every CU >= 2 blocks; below that the 64-channel block (NT = 2), and for
+    // a single 32-channel tile (DCN offset convs) the small block keeps the most CUs busy.
+    if (variant == 0) {
+        const long long blocks21 = (long long)a.B * cp_cdiv(a.H, 16) * cp_cdiv(a.W, WG_TW) * ntiles;
+        variant = ntiles == 1 ? 11 : (blocks21 >= 512 ? 21 : 12);
+    }
+    switch (variant) {
+        case 11: return launch_wino<1, 1, 16, 2>(a, s);
+        case 12: return launch_wino<1, 2, 16, 2>(a, s);
+        case 21: return launch_wino<2, 1, 16, 2>(a, s);
+        default: cp_set_error("conv3x3_winograd: unknown variant %d", variant); return 1;
+    }
+}
+
+// ---- weight transform: packed direct weights [rows >= Cout][9*C] (k = (ky*3+kx)*C + c)  ->  U = G g G^T,
+// laid out as the kernel's B fragments [xi][ntile][kc][nu][lane][4]:
+//   value(lane, j) = U[xi][nu][n = ntile*32 + lane%32][c = kc*8 + (lane/32)*4 + j]      (zero for n >= Cout)
+__global__ void wino_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int C, int Cout, int ntiles, long long total)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int KC = C >> 3;
+    long long t = idx;
+    const int j = (int)(t & 3); t >>= 2;
+    const int lane = (int)(t & 63); t >>= 6;
+    const int nu = (int)(t & 3); t >>= 2;
+    const int kc = (int)(t % KC); t /= KC;
+    const int nt = (int)(t % ntiles);
+    const int xi = (int)(t / ntiles);
+    const int n = nt * 32 + (lane & 31), c = kc * 8 + (lane >> 5) * 4 + j;
+    float r = 0.f;
+    if (n < Cout) {
+        const double G[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+        const float* g = w + (size_t)n * 9 * C + c;
+        double accd = 0.0;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) accd += G[xi][ky] * (double)g[(ky * 3 + kx) * C] * G[nu][kx];
+        r = (float)accd;
+    }
+    u[idx] = r;
+}
+
+extern "C" size_t cp_winograd_weight_floats(int C, int Cout)
+{
+    if (C <= 0 || Cout <= 0 || C % 8) return 0;
+    return (size_t)16 * ((Cout + 31) / 32) * 32 * C;
+}
+
+extern "C" int cp_winograd_pack_f32(const float* w, float* u, int C, int Cout, void* stream)
+{
+    CP_CHECK_ARG(w && u, "winograd_pack: null pointer");
+    CP_CHECK_ARG(C > 0 && C % 16 == 0 && Cout > 0, "winograd_pack: C=%d must be a positive multiple of 16 (Cout=%d)", C, Cout);
+    const int ntiles = (Cout + 31) / 32;
+    const long long total = (long long)cp_winograd_weight_floats(C, Cout);
+    hipLaunchKernelGGL(wino_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, u, C, Cout,
+                       ntiles, total);
+    CP_CHECK_LAUNCH("wino_pack_kernel");
+    return 0;
+}

@@ -208,14 +208,13 @@ struct cp_conv_desc {
     int tile;     // 0 = auto; otherwise BM*1000+BN of a specific instantiation (tuning / tests)
 };
 
-extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale,
-                             const float* shift, const float* res, float* out, void* stream)
+static int conv_args_from_desc(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale,
+                               const float* shift, const float* res, float* out, ConvArgs& a)
 {
     CP_CHECK_ARG(d && src && w && scale && shift && out, "conv2d: null pointer");
     CP_CHECK_ARG(d->nsrc >= 1 && d->nsrc <= IG_MAX_SRC, "conv2d: nsrc=%d", d->nsrc);
     CP_CHECK_ARG(d->K % IG_BK == 0 && d->K > 0, "conv2d: K=%d must be a positive multiple of 16", d->K);
     CP_CHECK_ARG(d->ldw % 16 == 0 && d->ldw >= d->Cout, "conv2d: ldw=%d (Cout=%d)", d->ldw, d->Cout);
-    ConvArgs a;
     int ctot = 0;
     for (int i = 0; i < IG_MAX_SRC; ++i) {
         a.src[i] = i < d->nsrc ? src[i] : nullptr;
@@ -241,6 +240,14 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
     a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1;
     CP_CHECK_ARG(a.M > 0 && (long long)d->B * d->H * d->W < (1ll << 31), "conv2d: bad problem size");
     CP_CHECK_ARG(!(res && d->outNCHW), "conv2d: residual with NCHW output is not supported");
+    return 0;
+}
+
+extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale,
+                             const float* shift, const float* res, float* out, void* stream)
+{
+    ConvArgs a;
+    if (int rc = conv_args_from_desc(d, src, w, scale, shift, res, out, a)) return rc;
     hipStream_t s = (hipStream_t)stream;
 
     int tile = d->tile;
@@ -283,5 +290,21 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
     }
     if (rc) return rc;
     CP_CHECK_LAUNCH("igemm_conv_kernel");
+    return 0;
+}
+
+// Winograd F(2x2,3x3) path (conv3x3_wino.hip): same descriptor, `u` = cp_winograd_pack_f32 output.
+// d->tile: 0 = auto, 1 / 2 = 32 / 64 output channels per block.
+extern "C" int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale,
+                                       const float* shift, const float* res, float* out, void* stream)
+{
+    ConvArgs a;
+    const float* srcs[1] = {src};
+    CP_CHECK_ARG(d && d->nsrc == 1 && !d->inNCHW, "conv3x3_winograd: one NHWC source expected");
+    if (int rc = conv_args_from_desc(d, srcs, u, scale, shift, res, out, a)) return rc;
+    const int rc = cp_launch_conv3x3_wino(a, (hipStream_t)stream, d->tile);
+    CP_CHECK_ARG(rc >= 0, "conv3x3_winograd: shape not eligible (3x3, stride 1, pad 1, NHWC, C %% 16 == 0)");
+    if (rc) return rc;
+    CP_CHECK_LAUNCH("conv3x3_wino_kernel");
     return 0;
 }

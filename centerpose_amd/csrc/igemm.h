@@ -60,6 +60,8 @@ struct ConvArgs {
 
 // conv3x3_patch.hip: returns -1 when the shape is not eligible, else 0 / error code
 int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s, int variant = 0);
+// conv3x3_wino.hip (a.w = Winograd-domain weights): same convention
+int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant = 0);
 
 // 16-byte load through an explicit GLOBAL address-space pointer.  A generic (flat) load also increments
 // lgkmcnt, so every `s_waitcnt lgkmcnt` guarding an LDS fragment read would wait for the prefetch as well.

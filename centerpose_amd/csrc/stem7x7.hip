@@ -67,19 +67,27 @@ __global__ __launch_bounds__(IG_THREADS) void stem7x7_kernel(const float* __rest
         float4 bf[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(Bs + (st * NOUT + j * 16 + il) * IG_LDK + g * 4);
+        // all A fragments of the step are read first (TM x 4 floats), the MFMAs follow behind a scheduling
+        // barrier: one exposed LDS round trip per step instead of one per 16-pixel tile
+        float av[TM][4];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int orow = wid * ROWS_W + i / (TW / 16), ocol = (i % (TW / 16)) * 16;
             const float* p = patch + ((rok ? c : 0) * PH + orow * S + (rok ? ky : 0)) * PW + ocol * S + a_col;
-            const float a0 = p[0], a1 = p[1], a2 = p[2], a3 = p[3];
+            av[i][0] = p[0]; av[i][1] = p[1]; av[i][2] = p[2]; av[i][3] = p[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, bf[j].x, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bf[j].y, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2, bf[j].z, acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bf[j].w, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][0], bf[j].x, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][1], bf[j].y, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][2], bf[j].z, acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][3], bf[j].w, acc[i][j], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---- epilogue: folded BN + ReLU, NHWC

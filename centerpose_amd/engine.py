@@ -8,6 +8,8 @@ allocation and no host synchronisation on the hot path.
 
 Replaces ``BackBoneWithHead.forward`` (lib/models/model.py:57-59) for dla_34 / res_50 / hrnet.
 """
+import os
+
 import torch
 
 from . import _lib, nets, ops
@@ -31,7 +33,9 @@ class PlanBuilder(nets.Graph):
         if isinstance(sigmoid_heads, bool):
             sigmoid_heads = ("hm", "hm_hp") if sigmoid_heads else ()
         self.sigmoid_heads = tuple(sigmoid_heads)
-        self.launches = []      # (kind, name, flops_per_batch, fn)
+        self.launches = []      # (kind, name, algorithmic flops_per_batch, fn); kind 'wino' = 3x3 conv on the Winograd kernel
+        # CP_WINOGRAD=0 keeps every 3x3 on the direct (patch) kernel: A/B switch for tests and profiling
+        self.winograd = os.environ.get("CP_WINOGRAD", "1") != "0"
         self.bytes_alloc = 0
         self._pool_cache = {}
         self.outputs = None
@@ -47,6 +51,12 @@ class PlanBuilder(nets.Graph):
 
     def bn(self, name):
         return tuple(self.w("%s.%s" % (name, s)) for s in ("weight", "bias", "running_mean", "running_var"))
+
+    def wino(self, wp, cin, cout, k=3, stride=1, pad=1, nsrc=1):
+        """Winograd-domain weights for an eligible 3x3/s1/p1 layer, else None (direct kernel)."""
+        if self.winograd and ops.wino_eligible(cin, k, stride, pad, nsrc):
+            return ops.pack_wino_weight(wp, cin, cout)
+        return None
 
     def add(self, kind, name, flops, fn):
         self.launches.append((kind, name, flops * self.B, fn))
@@ -70,10 +80,12 @@ class PlanBuilder(nets.Graph):
         act = ops.ACT_RELU if relu else ops.ACT_NONE
         ot = out.t
         ci = sum(a.C for a in xs)
+        u = None if stem else self.wino(wp, ci, co, k, stride, pad, len(xs))
 
         def fn():
-            ops.conv2d(srcs, wp, sc, sh, ot, kh=k, kw=k, stride=stride, pad=pad, cout=co, act=act, res=rt, in_nchw=stem)
-        self.add("conv", conv, 2 * Ho * Wo * co * ci * k * k, fn)
+            ops.conv2d(srcs, wp, sc, sh, ot, kh=k, kw=k, stride=stride, pad=pad, cout=co, act=act, res=rt, in_nchw=stem,
+                       wino=u)
+        self.add("wino" if u is not None else "conv", conv, 2 * Ho * Wo * co * ci * k * k, fn)
         return out
 
     def emit_maxpool(self, x, k, s, p):
@@ -95,13 +107,14 @@ class PlanBuilder(nets.Graph):
         wp = ops.pack_conv_weight(self.w(name + ".conv.weight"))
         sc, sh = ops.fold_bn(co, self.bn(name + ".actf.0"), self.w(name + ".conv.bias"), self.dev)
         xt, omt, ot = x.t, om.t, out.t
+        uom = self.wino(wom, x.C, 32)
 
         def fn_om():
-            ops.conv2d([xt], wom, som, hom, omt, kh=3, kw=3, stride=1, pad=1, cout=32)
+            ops.conv2d([xt], wom, som, hom, omt, kh=3, kw=3, stride=1, pad=1, cout=32, wino=uom)
 
         def fn():
             ops.dcn_v2(xt, omt, wp, sc, sh, ot, cout=co, om_sigmoid=True, act=ops.ACT_RELU)
-        self.add("conv", name + ".conv.conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9, fn_om)
+        self.add("wino" if uom is not None else "conv", name + ".conv.conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9, fn_om)
         self.add("dcn", name + ".conv", 2 * x.H * x.W * co * x.C * 9, fn)
         return out
 
@@ -152,10 +165,11 @@ class PlanBuilder(nets.Graph):
             b3 = torch.cat([self.w("%s.%s.0.bias" % (p, h)) for h, _ in nets.HEADS], 0)
             wp3 = ops.pack_conv_weight(w3)
             sc3, sh3 = ops.fold_bn(6 * hc, None, b3, self.dev)
+            u3 = self.wino(wp3, feat.C, 6 * hc)
 
             def fn3():
-                ops.conv2d([ft], wp3, sc3, sh3, mt, kh=3, kw=3, stride=1, pad=1, cout=6 * hc, act=ops.ACT_RELU)
-            self.add("conv", p + ".*.0", 2 * H * W * 6 * hc * feat.C * 9, fn3)
+                ops.conv2d([ft], wp3, sc3, sh3, mt, kh=3, kw=3, stride=1, pad=1, cout=6 * hc, act=ops.ACT_RELU, wino=u3)
+            self.add("wino" if u3 is not None else "conv", p + ".*.0", 2 * H * W * 6 * hc * feat.C * 9, fn3)
         for i, (h, n) in enumerate(nets.HEADS):
             o = torch.empty((self.B, n, H, W), dtype=torch.float32, device=self.dev)
             wp = ops.pack_conv_weight(self.w("%s.%s.2.weight" % (p, h)))
@@ -164,10 +178,11 @@ class PlanBuilder(nets.Graph):
             if per_head:
                 wp3h = ops.pack_conv_weight(self.w("%s.%s.0.weight" % (p, h)))
                 sc3h, sh3h = ops.fold_bn(hc, None, self.w("%s.%s.0.bias" % (p, h)), self.dev)
+                u3h = self.wino(wp3h, feat.C, hc)
 
-                def fn3h(wp3h=wp3h, sc3h=sc3h, sh3h=sh3h):
-                    ops.conv2d([ft], wp3h, sc3h, sh3h, mt, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU)
-                self.add("conv", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9, fn3h)
+                def fn3h(wp3h=wp3h, sc3h=sc3h, sh3h=sh3h, u3h=u3h):
+                    ops.conv2d([ft], wp3h, sc3h, sh3h, mt, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU, wino=u3h)
+                self.add("wino" if u3h is not None else "conv", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9, fn3h)
                 sl = mt
             else:
                 sl = mt[..., i * hc:(i + 1) * hc]

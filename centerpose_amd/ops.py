@@ -93,8 +93,11 @@ def _ld(t):
 
 
 def conv2d(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=ACT_NONE, res=None, out_nchw=False,
-           in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0):
+           in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0, wino=None):
     """Fused conv: out = act((sum_src conv(src)) * scale + shift [+ res]).
+
+    wino: Winograd-domain weights from `pack_wino_weight` -> the 3x3/s1/p1 launch goes through the fused
+    F(2x2,3x3) kernel (cp_conv3x3_winograd_f32); `tile` then selects 32 (1) / 64 (2) channels per block.
 
     srcs: list of NHWC tensors (concatenated along C) or one NCHW tensor when in_nchw.
     out : NHWC [B,OH,OW,>=cout] (or NCHW [B,cout,OH,OW] when out_nchw).
@@ -128,11 +131,36 @@ def conv2d(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=AC
         d.OH, d.OW, d.outLd = out.shape[1], out.shape[2], _ld(out)
     d.osy, d.osx, d.ooy, d.oox = out_scatter if out_scatter is not None else (1, 1, 0, 0)
     d.act, d.inNCHW, d.tile = act, 1 if in_nchw else 0, tile
+    if wino is not None:
+        assert len(srcs) == 1 and not in_nchw
+        rc = L.cp_conv3x3_winograd_f32(ctypes.byref(d), _lib.vptr(srcs[0]), _lib.ptr(wino), _lib.ptr(scale),
+                                       _lib.ptr(shift), _lib.vptr(res), _lib.vptr(out), _lib.stream())
+        _lib.check(rc, "cp_conv3x3_winograd_f32")
+        return out
     ptrs = (ctypes.c_void_p * 4)(*[_lib.vptr(s).value for s in srcs] + [None] * (4 - len(srcs)))
     rc = L.cp_conv2d_f32(ctypes.byref(d), ptrs, _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift),
                          _lib.vptr(res), _lib.vptr(out), _lib.stream())
     _lib.check(rc, "cp_conv2d_f32")
     return out
+
+
+def wino_eligible(cin, k, stride, pad, nsrc=1):
+    """3x3 / stride 1 / pad 1 single-source NHWC layers with >= 32 input channels go through the Winograd kernel
+    (16-channel layers stay on the direct patch kernel: measured 0.36 vs 0.24 ms for DLA level0)."""
+    return k == 3 and stride == 1 and pad == 1 and nsrc == 1 and cin % 16 == 0 and cin >= 32
+
+
+def pack_wino_weight(wp, cin, cout):
+    """packed direct 3x3 weights [ldw, 9*cin] (device) -> Winograd-domain U = G g G^T in the B-fragment order of
+    conv3x3_wino.hip ([xi][ntile][kc][nu][lane][4]); computed on the device in fp64, rounded once to fp32."""
+    L = _lib.lib()
+    assert wp.shape[1] == 9 * cin and wp.shape[0] >= cout and wp.is_contiguous()
+    L.cp_winograd_weight_floats.restype = ctypes.c_size_t
+    n = L.cp_winograd_weight_floats(cin, cout)
+    assert n > 0, "winograd: C must be a multiple of 16"
+    u = torch.empty((n,), dtype=torch.float32, device=wp.device)
+    _lib.check(L.cp_winograd_pack_f32(_lib.ptr(wp), _lib.ptr(u), cin, cout, _lib.stream()), "cp_winograd_pack_f32")
+    return u
 
 
 def dcn_v2(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, pad=1, dil=1, om_sigmoid=True,

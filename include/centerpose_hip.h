@@ -53,6 +53,19 @@ typedef struct cp_conv_desc {
 int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale, const float* shift,
                   const float* res, float* out, void* stream);
 
+/* ---- 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2,3x3) ---------------------------------
+ * Same layers and epilogue as cp_conv2d_f32 (the reference gets these from cuDNN, which also picks Winograd
+ * for fp32 3x3 under cudnn.benchmark = True, lib/detectors/base_detector.py / main.py); 16 multiplies per
+ * 2x2 output tile and (cin, cout) instead of 36, fp32 throughout (error ~3e-6 relative, below the direct kernel's).
+ * cp_winograd_pack_f32: packed direct weights w [rows >= Cout][9*C] (k = (ky*3+kx)*C + c, as for cp_conv2d_f32)
+ *   -> u [cp_winograd_weight_floats(C, Cout)] = G g G^T in the kernel's MFMA B-fragment order; C % 16 == 0.
+ * cp_conv3x3_winograd_f32: d as for cp_conv2d_f32 with nsrc = 1, kh = kw = 3, stride 1, pad 1, NHWC in/out
+ *   (returns 1 for any other shape); d->tile: 0 = auto, MT*10+NT in {11, 12, 21} forces a block shape. */
+size_t cp_winograd_weight_floats(int C, int Cout);
+int cp_winograd_pack_f32(const float* w, float* u, int C, int Cout, void* stream);
+int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
+                            const float* res, float* out, void* stream);
+
 /* ---- fused DCNv2 forward -------------------------------------------------------------------------
  * Replaces dcn_v2_forward / dcn_v2_cuda_forward (DCNv2/src/dcn_v2.h:9-39, src/cuda/dcn_v2_cuda.cu:42-172,
  * src/cuda/dcn_v2_im2col_cuda.cu:25-54,125-195) plus the BN + ReLU of DeformConv (pose_dla_dcn.py:345-348).

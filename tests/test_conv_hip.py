@@ -256,6 +256,37 @@ def test_conv3x3_patch_kernel(cin, cout, hw, B):
     _close(out[..., :cout].permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("cin,cout,hw,B,nt", [(16, 32, (24, 40), 2, 0), (64, 64, (20, 28), 3, 11), (64, 64, (20, 28), 3, 12),
+                                              (64, 64, (20, 28), 3, 21), (32, 27, (16, 16), 2, 0), (32, 27, (19, 16), 2, 11),
+                                              (48, 128, (9, 35), 2, 12), (48, 128, (9, 35), 2, 21), (128, 192, (16, 16), 2, 0),
+                                              (64, 256, (32, 32), 1, 21), (256, 96, (8, 8), 2, 11)])
+def test_conv3x3_winograd_kernel(cin, cout, hw, B, nt):
+    """fused Winograd F(2x2,3x3) kernel: odd sizes, ragged tiles, residual, ragged channel tiles, scalar-store tail;
+    against the torch-CPU fp32 direct convolution.  Tolerance 2e-4 * max|ref| like the direct kernels (measured
+    error is ~3e-6 relative: fp32 transforms, fp32 MFMA accumulate)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(7 * cin + cout)
+    H, W = hw
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bn = _rand_bn(g, cout)
+    res = torch.randn(B, cout, H, W, generator=g) if cout != 96 else None
+    y = _ref_bn(F.conv2d(x, w, None, 1, 1), bn)
+    ref = F.relu(y + res) if res is not None else y
+    wp = ops.pack_conv_weight(w.cuda())
+    u = ops.pack_wino_weight(wp, cin, cout)
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    ld = 32 if cout == 27 else cout
+    buf = torch.full((B, H, W, ld), float("nan"), device="cuda")
+    out = buf[..., :cout]
+    resn = res.permute(0, 2, 3, 1).contiguous().cuda() if res is not None else None
+    ops.conv2d([_nhwc(x)], wp, sc, sh, out, kh=3, kw=3, stride=1, pad=1, cout=cout,
+               act=ops.ACT_RELU if res is not None else ops.ACT_NONE, res=resn, tile=nt, wino=u)
+    _close(out.permute(0, 3, 1, 2), ref)
+    if ld != cout:
+        assert torch.isnan(buf[..., cout:]).all()      # nothing stored past Cout
+
+
 @pytest.mark.parametrize("cout,s,hw", [(16, 1, (40, 72)), (64, 2, (37, 70)), (16, 1, (512, 512)), (64, 2, (128, 96))])
 def test_stem7x7_kernel(cout, s, hw):
     """dedicated 7x7 stem (pose_dla_dcn.py:228-232 / msra_resnet.py:118-121) vs torch-CPU."""
