@@ -54,6 +54,97 @@ __device__ __forceinline__ int wg_div(int n, int d, unsigned magic) { return d =
 
 __device__ __forceinline__ wg_v4 wg_lds4(const float* p) { return *reinterpret_cast<const wg_v4*>(p); }
 
+// One accumulator group (32 Winograd tiles x 32 channels, the wave's four frequencies) -> output pixels.
+// Y = A^T M A: the nu-sum is done in registers, the xi-sum across the four waves through `red` (the caller
+// guarantees nobody still uses that LDS region), then scale/shift (+residual) + activation, float4 NHWC stores.
+__device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, const f32x16 (&acc)[4], int xi, int h, int m, int tid,
+                                               int b, int yb, int x0, int tile, bool store)
+{
+    const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
+    const bool vec_ok = (a.outLd & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
+                        (!a.res || ((a.resLd & 3) == 0 && (((size_t)a.res) & 15) == 0));
+    // The MFMA is issued as D[channel][tile] (A = U fragment, B = V fragment), so a lane holds 4 x 4 consecutive
+    // channels (8j + 4h .. +3) of tile m: the reduction buffer red[(xi*2+bcol)*32 + tile][channel] is written with
+    // ds_write_b128 (pitch 36 floats: the 16 tiles of a b128 lane group land on 16 distinct 4-bank groups).
+    float* wp = red + (xi * 64 + m) * WG_LDR + 4 * h;
+    {
+        const f32x16 s0 = acc[0] + acc[1] + acc[2];
+        const f32x16 s1 = acc[1] - acc[2] - acc[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<wg_v4*>(wp + 8 * j) = (wg_v4){s0[4 * j], s0[4 * j + 1], s0[4 * j + 2], s0[4 * j + 3]};
+            *reinterpret_cast<wg_v4*>(wp + 32 * WG_LDR + 8 * j) = (wg_v4){s1[4 * j], s1[4 * j + 1], s1[4 * j + 2], s1[4 * j + 3]};
+        }
+    }
+    // per-thread output items (tile mi, column bb, 4 channels n4); their scale / shift / residual loads are issued
+    // BEFORE the barrier so that the global-memory latency overlaps the cross-wave hand-over
+    int itn[2], itox[2], itoy[2], itrd[2];
+    bool itok[2], itvec[2];
+    size_t itpix[2];
+    wg_v4 sc[2], sh[2], rr[2][2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + it * IG_THREADS;
+        const int n4 = item & 7, bb = (item >> 3) & 1, mi = item >> 4;
+        itn[it] = tile * 32 + n4 * 4;
+        itox[it] = x0 + 2 * (mi & 7) + bb;
+        itoy[it] = yb + 2 * (mi >> 3);
+        itrd[it] = (bb * 32 + mi) * WG_LDR + n4 * 4;
+        itok[it] = store && itox[it] < a.W && itn[it] < a.Cout && itoy[it] < a.H;
+        itvec[it] = itok[it] && vec_ok && itn[it] + 3 < a.Cout;
+        itpix[it] = ((size_t)b * a.H + itoy[it]) * a.W + itox[it];
+        if (itvec[it]) {
+            sc[it] = *reinterpret_cast<const wg_v4*>(a.scale + itn[it]);
+            sh[it] = *reinterpret_cast<const wg_v4*>(a.shift + itn[it]);
+            if (a.res) {
+                rr[it][0] = *reinterpret_cast<const wg_v4*>(a.res + itpix[it] * a.resLd + itn[it]);
+                if (itoy[it] + 1 < a.H) rr[it][1] = *reinterpret_cast<const wg_v4*>(a.res + (itpix[it] + a.W) * a.resLd + itn[it]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (!itok[it]) continue;
+        const float* rp = red + itrd[it];
+        const wg_v4 q0 = wg_lds4(rp), q1 = wg_lds4(rp + 64 * WG_LDR), q2 = wg_lds4(rp + 128 * WG_LDR), q3 = wg_lds4(rp + 192 * WG_LDR);
+        wg_v4 yv[2];
+        yv[0] = (q0 + q1) + q2;
+        yv[1] = (q1 - q2) - q3;
+        const int n = itn[it];
+        if (itvec[it]) {
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                if (itoy[it] + aa >= a.H) continue;
+                const size_t opix = itpix[it] + (size_t)aa * a.W;
+                wg_v4 v = __builtin_elementwise_fma(yv[aa], sc[it], sh[it]);
+                if (a.res) v += rr[it][aa];
+                if (relu) v = __builtin_elementwise_max(v, (wg_v4){0.f, 0.f, 0.f, 0.f});
+                else if (sigm) {
+                    v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
+                    v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
+                }
+                *reinterpret_cast<wg_v4*>(a.out + opix * a.outLd + n) = v;
+            }
+        } else {
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                if (itoy[it] + aa >= a.H) continue;
+                const size_t opix = itpix[it] + (size_t)aa * a.W;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (n + k >= a.Cout) break;
+                    float w_ = yv[aa][k] * a.scale[n + k] + a.shift[n + k];
+                    if (a.res) w_ += a.res[opix * a.resLd + n + k];
+                    if (relu) w_ = fmaxf(w_, 0.f);
+                    else if (sigm) w_ = 1.0f / (1.0f + __expf(-w_));
+                    a.out[opix * a.outLd + n + k] = w_;
+                }
+            }
+        }
+    }
+}
+
 // MT = 32-tile M sets per block (block = 8*MT x 16 output pixels), NT = 32-channel N tiles per block,
 // KS = channels per LDS stage, NB = U-fragment register sets (prefetch distance NB-1 chunks).
 // The U fragment of a chunk is used by MT MFMAs, the V fragment by NT: U traffic per flop ~ 1/MT,
@@ -196,10 +287,10 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : 2) void
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float4 bb = bq[ch % NB][nt][nu];
-                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[nu].x, bb.x, acc[mt][nt][nu], 0, 0, 0);
-                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(vl[nu].y, bb.y, acc[mt][nt][nu], 0, 0, 0);
-                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[nu].x, bb.z, acc[mt][nt][nu], 0, 0, 0);
-                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(vh[nu].y, bb.w, acc[mt][nt][nu], 0, 0, 0);
+                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.x, vl[nu].x, acc[mt][nt][nu], 0, 0, 0);
+                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.y, vl[nu].y, acc[mt][nt][nu], 0, 0, 0);
+                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.z, vh[nu].x, acc[mt][nt][nu], 0, 0, 0);
+                    acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.w, vh[nu].y, acc[mt][nt][nu], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -208,77 +299,135 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : 2) void
     }
 
     // ---- epilogue: Y = A^T M A.  nu-sum in registers, xi-sum across waves through LDS.
-    const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
-    const bool vec_ok = (a.outLd & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
-                        (!a.res || ((a.resLd & 3) == 0 && (((size_t)a.res) & 15) == 0));
-    float* red = smem;
-    // fixed per thread: reduction-buffer write base and the two output items (tile mi, column bb, 4 channels n4)
-    const int wbase = (xi * 64 + 4 * h) * WG_LDR + m;       // row (xi*2+b)*32 + ig_row(r): + b*32*LDR + ((r&3)+8*(r>>2))*LDR
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        if (mt + nt) __syncthreads();
-        {
-            const f32x16 s0 = acc[mt][nt][0] + acc[mt][nt][1] + acc[mt][nt][2];
-            const f32x16 s1 = acc[mt][nt][1] - acc[mt][nt][2] - acc[mt][nt][3];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                red[wbase + ((r & 3) + 8 * (r >> 2)) * WG_LDR] = s0[r];
-                red[wbase + (32 + (r & 3) + 8 * (r >> 2)) * WG_LDR] = s1[r];
-            }
+        for (int nt = 0; nt < NT; ++nt) {
+            if (mt + nt) __syncthreads();
+            wg_output_tile(a, smem, acc[mt][nt], xi, h, m, tid, b, y0 + mt * 8, x0, nb * NT + nt, nb * NT + nt < NTILES);
         }
-        __syncthreads();
-        const int tile = nb * NT + nt;
-        if (tile >= NTILES) continue;
+}
+
+// ---- V-stationary variant for 64 input channels (the six head 3x3 convs, 64 -> 256 each, 28 % of DLA-34's FLOPs) ----
+// With C = 64 the wave's whole transformed input V[4 nu][32 tiles][64 ch] is 128 VGPRs: it is formed ONCE per
+// block (whole 64-channel halo patch staged in LDS in one go), then the block loops over its output-channel tiles
+// with an inner loop that is nothing but U-fragment loads and MFMAs - no LDS reads, no transform VALU, no barrier,
+// no patch re-staging per channel tile (the generic kernel re-stages the patch for each of the 8 tiles of a head).
+// Each VMEM instruction costs ~23 cycles and each VALU 4 cycles of matrix-pipe time (tools/micro/wino_loop.hip),
+// so this removes most of the non-MFMA issue slots.  LDS: 51 KB patch, re-used as the reduction buffer.
+#define WGV_C 64
+#define WGV_CGS (WGV_C / 4)
+#define WGV_F4 (10 * WG_PW * WGV_CGS)                       // 2880 float4
+#define WGV_SLOTS ((WGV_F4 + IG_THREADS - 1) / IG_THREADS)  // 12
+#define WGV_CG (10 * WG_PWP * 4)                            // floats per 4-channel plane
+#define WGV_SMEM_FLOATS (2 * WG_RED)                        // two reduction buffers (73.7 KB) >= the 51.2 KB patch
+
+__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const ConvArgs a, const WgGrid gd, int NL)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    const int NTILES = (a.Cout + 31) >> 5;
+    int t_ = ig_xcd_remap(blockIdx.x, gridDim.x), q_;
+    q_ = wg_div(t_, gd.ntb, gd.mNtb); const int ng = t_ - q_ * gd.ntb; t_ = q_;
+    q_ = wg_div(t_, gd.tilesX, gd.mTx); const int tx = t_ - q_ * gd.tilesX; t_ = q_;
+    q_ = wg_div(t_, gd.tilesY, gd.mTy); const int ty = t_ - q_ * gd.tilesY;
+    const int b = q_;
+    const int y0 = ty * 8, x0 = tx * WG_TW;
+    const int ld = a.srcLd[0];
+    const float* __restrict__ x = a.src[0];
+    const int nt0 = ng * NL, nt1 = nt0 + NL < NTILES ? nt0 + NL : NTILES;
+
+    // ---- stage the whole 64-channel halo patch: [cg 16][py 10][px ^ f(py)][4]
+    {
+        float4 rg[WGV_SLOTS];
+        int lo[WGV_SLOTS];
+        bool ok[WGV_SLOTS];
 #pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const int item = tid + it * IG_THREADS;
-            const int n4 = item & 7, bb = (item >> 3) & 1, mi = item >> 4;
-            const int n = tile * 32 + n4 * 4;
-            const int ox = x0 + 2 * (mi & 7) + bb;
-            if (ox >= a.W || n >= a.Cout) continue;
-            const float* rp = red + (bb * 32 + mi) * WG_LDR + n4 * 4;
-            const wg_v4 q0 = wg_lds4(rp), q1 = wg_lds4(rp + 64 * WG_LDR), q2 = wg_lds4(rp + 128 * WG_LDR),
-                        q3 = wg_lds4(rp + 192 * WG_LDR);
-            wg_v4 yv[2];
-            yv[0] = (q0 + q1) + q2;
-            yv[1] = (q1 - q2) - q3;
-            const int oy0 = y0 + mt * 8 + 2 * (mi >> 3);
-            const size_t opix0 = ((size_t)b * a.H + oy0) * a.W + ox;
-            if (vec_ok && n + 3 < a.Cout) {
-                const wg_v4 sc = *reinterpret_cast<const wg_v4*>(a.scale + n);
-                const wg_v4 sh = *reinterpret_cast<const wg_v4*>(a.shift + n);
-#pragma unroll
-                for (int aa = 0; aa < 2; ++aa) {
-                    if (oy0 + aa >= a.H) continue;
-                    const size_t opix = opix0 + (size_t)aa * a.W;
-                    wg_v4 v = __builtin_elementwise_fma(yv[aa], sc, sh);
-                    if (a.res) v += *reinterpret_cast<const wg_v4*>(a.res + opix * a.resLd + n);
-                    if (relu) v = __builtin_elementwise_max(v, (wg_v4){0.f, 0.f, 0.f, 0.f});
-                    else if (sigm) {
-                        v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
-                        v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
-                    }
-                    *reinterpret_cast<wg_v4*>(a.out + opix * a.outLd + n) = v;
-                }
-            } else {
-#pragma unroll
-                for (int aa = 0; aa < 2; ++aa) {
-                    if (oy0 + aa >= a.H) continue;
-                    const size_t opix = opix0 + (size_t)aa * a.W;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        if (n + k >= a.Cout) break;
-                        float w_ = yv[aa][k] * a.scale[n + k] + a.shift[n + k];
-                        if (a.res) w_ += a.res[opix * a.resLd + n + k];
-                        if (relu) w_ = fmaxf(w_, 0.f);
-                        else if (sigm) w_ = 1.0f / (1.0f + __expf(-w_));
-                        a.out[opix * a.outLd + n + k] = w_;
-                    }
-                }
-            }
+        for (int s = 0; s < WGV_SLOTS; ++s) {
+            const int idx = tid + s * IG_THREADS;
+            const int pp = idx / WGV_CGS, q = idx % WGV_CGS;
+            const int py = pp / WG_PW, px = pp - py * WG_PW;
+            const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+            const bool inl = idx < WGV_F4;
+            ok[s] = inl && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+            const int go = ok[s] ? ((b * a.H + gy) * a.W + gx) * ld + q * 4 : 0;
+            lo[s] = inl ? ((q * 10 + py) * WG_PWP + (px ^ ((py >> 1) & 1))) * 4 : -1;
+            rg[s] = ig_ldg4(x + go);
         }
+#pragma unroll
+        for (int s = 0; s < WGV_SLOTS; ++s)
+            if (lo[s] >= 0) {
+                float4 v = rg[s];
+                if (!ok[s]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(smem + lo[s]) = v;
+            }
+    }
+    // first U chunk in flight under the transform
+    const float* up = a.w + ((size_t)(xi * NTILES + nt0) * (WGV_C / 8)) * 1024 + lane * 4;
+    const int nlin = (nt1 - nt0) * (WGV_C / 8);              // chunks this block walks through, contiguous in U
+    float4 bq[2][4];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu) bq[0][nu] = ig_ldg4(up + nu * 256);
+    __syncthreads();
+
+    // ---- V = B^T d B for the wave's row xi, all 8 chunks, kept in registers
+    const int rA = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+    const int rB = xi == 2 ? 1 : (xi == 3 ? 3 : 2);
+    const float sg1 = xi == 1 ? 1.f : -1.f;
+    const wg_v2 sg = {sg1, sg1};
+    const int tyy = m >> 3, txx = m & 7;
+    const int fA = (tyy + (rA >> 1)) & 1, fB = (tyy + (rB >> 1)) & 1;
+    const int baseA = ((2 * tyy + rA) * WG_PWP + 2 * txx) * 4 + h * WGV_CG;
+    const int baseB = ((2 * tyy + rB) * WG_PWP + 2 * txx) * 4 + h * WGV_CG;
+    const int offAe = baseA + fA * 4, offAo = baseA - fA * 4, offBe = baseB + fB * 4, offBo = baseB - fB * 4;
+    wg_v2 vl[WGV_C / 8][4], vh[WGV_C / 8][4];
+#pragma unroll
+    for (int kc = 0; kc < WGV_C / 8; ++kc) {
+        const float* pc = smem + kc * 2 * WGV_CG;
+        wg_v2 tl[4], th[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const wg_v4 da = wg_lds4(pc + ((j & 1) ? offAo : offAe) + j * 4);
+            const wg_v4 db = wg_lds4(pc + ((j & 1) ? offBo : offBe) + j * 4);
+            tl[j] = __builtin_elementwise_fma(sg, db.xy, da.xy);
+            th[j] = __builtin_elementwise_fma(sg, db.zw, da.zw);
+        }
+        vl[kc][0] = tl[0] - tl[2]; vh[kc][0] = th[0] - th[2];
+        vl[kc][1] = tl[1] + tl[2]; vh[kc][1] = th[1] + th[2];
+        vl[kc][2] = tl[2] - tl[1]; vh[kc][2] = th[2] - th[1];
+        vl[kc][3] = tl[1] - tl[3]; vh[kc][3] = th[1] - th[3];
+    }
+
+    __syncthreads();                // every wave has read its rows of the patch: the region becomes the reduction buffers
+    // ---- output-channel tiles: U streams through two register sets, V stays put
+    int lin = 0;
+#pragma unroll 1
+    for (int nt = nt0; nt < nt1; ++nt) {
+        f32x16 acc[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nu][r] = 0.f;
+#pragma unroll
+        for (int kc = 0; kc < WGV_C / 8; ++kc) {
+            ++lin;
+            const float* un = up + (size_t)(lin < nlin ? lin : nlin - 1) * 1024;      // next chunk (next tile's first after the 8th)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) bq[(kc + 1) & 1][nu] = ig_ldg4(un + nu * 256);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                const float4 bb = bq[kc & 1][nu];
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.x, vl[kc][nu].x, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.y, vl[kc][nu].y, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.z, vh[kc][nu].x, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.w, vh[kc][nu].y, acc[nu], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // two reduction buffers: tile i+2 overwrites buffer i&1 only after the barrier inside tile i+1's output stage
+        wg_output_tile(a, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, b, y0, x0, nt, true);
     }
 }
 
@@ -302,6 +451,30 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
     return 0;
 }
 
+static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups)
+{
+    const int smem = WGV_SMEM_FLOATS * 4;
+    static bool attr = false;
+    if (!attr) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_vs64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) { cp_set_error("conv3x3_winograd: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
+        attr = true;
+    }
+    WgGrid gd;
+    gd.tilesX = cp_cdiv(a.W, WG_TW); gd.tilesY = cp_cdiv(a.H, 8);
+    const int ntiles = (a.Cout + 31) / 32;
+    if (ngroups < 1) ngroups = 1;
+    if (ngroups > ntiles) ngroups = ntiles;
+    const int NL = (ntiles + ngroups - 1) / ngroups;
+    gd.ntb = (ntiles + NL - 1) / NL;
+    gd.mNtb = wg_magic(gd.ntb); gd.mTx = wg_magic(gd.tilesX); gd.mTy = wg_magic(gd.tilesY);
+    const long long grid = (long long)a.B * gd.tilesX * gd.tilesY * gd.ntb;
+    const long long dmax = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
+    if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd: grid %lld too large", grid); return 1; }
+    hipLaunchKernelGGL(conv3x3_wino_vs64_kernel, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd, NL);
+    return 0;
+}
+
 // a.w = Winograd-domain weights from cp_winograd_pack_f32.  Returns -1 when the shape is not eligible.
 int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
 {
@@ -316,8 +489,13 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
     // a single 32-channel tile (DCN offset convs) the small block keeps the most CUs busy.
     if (variant == 0) {
         const long long blocks21 = (long long)a.B * cp_cdiv(a.H, 16) * cp_cdiv(a.W, WG_TW) * ntiles;
-        variant = ntiles == 1 ? 11 : (blocks21 >= 512 ? 21 : 12);
+        const long long blocks_vs = (long long)a.B * cp_cdiv(a.H, 8) * cp_cdiv(a.W, WG_TW);
+        // 64 input channels and >= 4 channel tiles (the head convs): V-stationary kernel, one block per spatial tile
+        if (a.srcC[0] == 64 && ntiles >= 4 && blocks_vs >= 512) variant = 6401;
+        else variant = ntiles == 1 ? 11 : (blocks21 >= 512 ? 21 : 12);
     }
+    // 64xx: V-stationary kernel (C == 64), xx = number of channel-tile groups per spatial tile (0 -> 1)
+    if (variant >= 6400 && variant < 6500) return a.srcC[0] == 64 ? launch_wino_vs64(a, s, variant - 6400) : -1;
     switch (variant) {
         case 11: return launch_wino<1, 1, 16, 2>(a, s);
         case 12: return launch_wino<1, 2, 16, 2>(a, s);

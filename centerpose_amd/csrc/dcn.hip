@@ -17,6 +17,7 @@
 #include "igemm.h"
 
 #define DCN_MAX_TAPS 9
+typedef float dcn_v2 __attribute__((ext_vector_type(2)));
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MF>
 __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs a)
@@ -112,13 +113,17 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
 #pragma unroll
         for (int s = 0; s < T::A_SLOTS; ++s) {
             const int pl = (tid >> 2) + s * 64;
+            // packed fp32 (v_pk_mul / v_pk_fma, weight broadcast through op_sel): 8 VALU instructions per float4
+            // instead of 16 -- every VALU instruction costs ~4 cycles of matrix-pipe time (tools/micro/wino_loop.hip)
             const float4 w = wq[s];
-            float4 v;
-            v.x = w.x * c00[s].x + w.y * c01[s].x + w.z * c10[s].x + w.w * c11[s].x;
-            v.y = w.x * c00[s].y + w.y * c01[s].y + w.z * c10[s].y + w.w * c11[s].y;
-            v.z = w.x * c00[s].z + w.y * c01[s].z + w.z * c10[s].z + w.w * c11[s].z;
-            v.w = w.x * c00[s].w + w.y * c01[s].w + w.z * c10[s].w + w.w * c11[s].w;
-            *reinterpret_cast<float4*>(As + pl * IG_LDK + q * 4) = v;
+            const dcn_v2 wx = {w.x, w.x}, wy = {w.y, w.y}, wz = {w.z, w.z}, ww = {w.w, w.w};
+            const dcn_v2 lo = __builtin_elementwise_fma(ww, (dcn_v2){c11[s].x, c11[s].y},
+                              __builtin_elementwise_fma(wz, (dcn_v2){c10[s].x, c10[s].y},
+                              __builtin_elementwise_fma(wy, (dcn_v2){c01[s].x, c01[s].y}, wx * (dcn_v2){c00[s].x, c00[s].y})));
+            const dcn_v2 hi = __builtin_elementwise_fma(ww, (dcn_v2){c11[s].z, c11[s].w},
+                              __builtin_elementwise_fma(wz, (dcn_v2){c10[s].z, c10[s].w},
+                              __builtin_elementwise_fma(wy, (dcn_v2){c01[s].z, c01[s].w}, wx * (dcn_v2){c00[s].z, c00[s].w})));
+            *reinterpret_cast<float4*>(As + pl * IG_LDK + q * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
     };
 
