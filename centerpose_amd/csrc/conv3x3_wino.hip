@@ -24,6 +24,7 @@
 // Arithmetic is fp32 throughout; the result differs from the direct convolution by ordinary fp32
 // rounding (~1e-6 relative, measured in tests/test_conv_hip.py), far inside the path's 1e-3 bar.
 #include "igemm.h"
+#include <cstdlib>
 
 #define WG_TW 16
 #define WG_PW (WG_TW + 2)
@@ -150,7 +151,7 @@ __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, co
 // The U fragment of a chunk is used by MT MFMAs, the V fragment by NT: U traffic per flop ~ 1/MT,
 // LDS reads + transform VALU per flop ~ 1/NT.
 template <int MT, int NT, int KS, int NB>
-__global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : 2) void conv3x3_wino_kernel(const ConvArgs a, const WgGrid gd)
+__global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * NT >= 4 ? 1 : 2)) void conv3x3_wino_kernel(const ConvArgs a, const WgGrid gd)
 {
     using Geo = WgGeo<MT, KS>;
     constexpr int CPS = KS / 8, U = CPS * MT;          // chunks / units per stage
@@ -438,7 +439,11 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
 {
     auto kern = conv3x3_wino_kernel<MT, NT, KS, NB>;
     using Geo = WgGeo<MT, KS>;
-    const int smem = Geo::SMEM_FLOATS * 4;
+    const int smem = getenv("CP_WG_SMEM") ? atoi(getenv("CP_WG_SMEM")) : Geo::SMEM_FLOATS * 4;
+    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+        cp_set_error("conv3x3_winograd: cannot reserve %d B LDS", smem);
+        return 2;
+    }
     WgGrid gd;
     gd.tilesX = cp_cdiv(a.W, WG_TW); gd.tilesY = cp_cdiv(a.H, Geo::TH);
     const int ntiles = (a.Cout + 31) / 32;
@@ -453,7 +458,7 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
 
 static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups)
 {
-    const int smem = WGV_SMEM_FLOATS * 4;
+    const int smem = getenv("CP_VS_SMEM") ? atoi(getenv("CP_VS_SMEM")) : WGV_SMEM_FLOATS * 4;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_vs64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
@@ -486,13 +491,14 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
     const int ntiles = (a.Cout + 31) / 32;
     // variant = MT*10 + NT (tuning / tests); 0 = auto.  Measured on MI355X (tools/bench_conv.py, B = 16): the 16x16-pixel
     // block (MT = 2) wins while it still gives every CU >= 2 blocks; below that the 64-channel block (NT = 2), and for
-    // a single 32-channel tile (DCN offset convs) the small block keeps the most CUs busy.
+    // a single 32-channel tile (DCN offset convs) the small block keeps the most CUs busy; in between, the
+    // 16x16-pixel x 64-channel block (MT = NT = 2, one wave per SIMD with 512 VGPRs) is 3-8 % ahead.
     if (variant == 0) {
         const long long blocks21 = (long long)a.B * cp_cdiv(a.H, 16) * cp_cdiv(a.W, WG_TW) * ntiles;
         const long long blocks_vs = (long long)a.B * cp_cdiv(a.H, 8) * cp_cdiv(a.W, WG_TW);
         // 64 input channels and >= 4 channel tiles (the head convs): V-stationary kernel, one block per spatial tile
         if (a.srcC[0] == 64 && ntiles >= 4 && blocks_vs >= 512) variant = 6401;
-        else variant = ntiles == 1 ? 11 : (blocks21 >= 512 ? 21 : 12);
+        else variant = ntiles == 1 ? 11 : (blocks21 >= 2048 ? 21 : (blocks21 >= 512 && ntiles % 2 == 0 ? 22 : 12));
     }
     // 64xx: V-stationary kernel (C == 64), xx = number of channel-tile groups per spatial tile (0 -> 1)
     if (variant >= 6400 && variant < 6500) return a.srcC[0] == 64 ? launch_wino_vs64(a, s, variant - 6400) : -1;
@@ -500,6 +506,8 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
         case 11: return launch_wino<1, 1, 16, 2>(a, s);
         case 12: return launch_wino<1, 2, 16, 2>(a, s);
         case 21: return launch_wino<2, 1, 16, 2>(a, s);
+        case 41: return launch_wino<4, 1, 16, 2>(a, s);
+        case 22: return launch_wino<2, 2, 16, 2>(a, s);
         default: cp_set_error("conv3x3_winograd: unknown variant %d", variant); return 1;
     }
 }

@@ -261,7 +261,8 @@ def test_conv3x3_patch_kernel(cin, cout, hw, B):
                                               (48, 128, (9, 35), 2, 12), (48, 128, (9, 35), 2, 21), (128, 192, (16, 16), 2, 0),
                                               (64, 256, (32, 32), 1, 21), (256, 96, (8, 8), 2, 11),
                                               (64, 256, (20, 28), 2, 6401), (64, 256, (9, 35), 1, 6403), (64, 64, (16, 16), 2, 6402),
-                                              (64, 27, (19, 16), 2, 6400), (64, 96, (8, 8), 2, 6408)])
+                                              (64, 27, (19, 16), 2, 6400), (64, 96, (8, 8), 2, 6408),
+                                              (48, 128, (37, 35), 2, 41), (64, 64, (20, 28), 3, 22)])
 def test_conv3x3_winograd_kernel(cin, cout, hw, B, nt):
     """fused Winograd F(2x2,3x3) kernel: odd sizes, ragged tiles, residual, ragged channel tiles, scalar-store tail;
     against the torch-CPU fp32 direct convolution.  Tolerance 2e-4 * max|ref| like the direct kernels (measured
