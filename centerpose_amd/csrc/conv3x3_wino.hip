@@ -255,6 +255,16 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
     stage_store(smem);
     __syncthreads();
 
+    wg_v4 dAp[4], dBp[4];                     // raw rows carried across the MFMAs (PIPE only)
+    auto read_d = [&](const float* buf, int ch, int mt, wg_v4 (&dA)[4], wg_v4 (&dB)[4]) __attribute__((always_inline)) {
+        const float* pc = buf + ch * 2 * Geo::CG + mt * (8 * WG_PWP * 4);       // tile set mt: 4 tile rows down
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            dA[j] = wg_lds4(pc + ((j & 1) ? offAo : offAe) + j * 4);
+            dB[j] = wg_lds4(pc + ((j & 1) ? offBo : offBe) + j * 4);
+        }
+    };
+    constexpr bool PIPE = MT * NT >= 4;       // one wave per SIMD: nobody else hides the LDS round trip
     const int nstage = C / KS;
 #pragma unroll 1
     for (int st = 0; st < nstage; ++st) {
@@ -267,15 +277,30 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
             // vmcnt retires in order: the next stage's patch loads (HBM latency) must be YOUNGER than every U
             // fragment load that is consumed inside this stage, or each such wait would also wait for the patch
             if (u == (NB - 2) * MT && more) stage_load((st + 1) * KS);
-            // V = B^T d B for the wave's row xi: packed fp32 math, 16 VALU instructions per unit
-            const float* pc = buf + ch * 2 * Geo::CG + mt * (8 * WG_PWP * 4);       // tile set mt: 4 tile rows down
+            // V = B^T d B for the wave's row xi: packed fp32 math, 16 VALU instructions per unit.  The raw rows of
+            // unit u+1 (same stage buffer) are read right after unit u's transform has consumed the registers, i.e.
+            // BEFORE unit u's MFMAs: the LDS latency hides behind them (matters at one wave per SIMD).
             wg_v2 tl[4], th[4];
+            if constexpr (PIPE) {
+                if (u == 0) read_d(buf, 0, 0, dAp, dBp);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const wg_v4 da = wg_lds4(pc + ((j & 1) ? offAo : offAe) + j * 4);
-                const wg_v4 db = wg_lds4(pc + ((j & 1) ? offBo : offBe) + j * 4);
-                tl[j] = __builtin_elementwise_fma(sg, db.xy, da.xy);
-                th[j] = __builtin_elementwise_fma(sg, db.zw, da.zw);
+                for (int j = 0; j < 4; ++j) {
+                    tl[j] = __builtin_elementwise_fma(sg, dBp[j].xy, dAp[j].xy);
+                    th[j] = __builtin_elementwise_fma(sg, dBp[j].zw, dAp[j].zw);
+                }
+                if (u + 1 < U) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    read_d(buf, (u + 1) / MT, (u + 1) % MT, dAp, dBp);
+                }
+            } else {
+                const float* pc = buf + ch * 2 * Geo::CG + mt * (8 * WG_PWP * 4);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const wg_v4 da = wg_lds4(pc + ((j & 1) ? offAo : offAe) + j * 4);
+                    const wg_v4 db = wg_lds4(pc + ((j & 1) ? offBo : offBe) + j * 4);
+                    tl[j] = __builtin_elementwise_fma(sg, db.xy, da.xy);
+                    th[j] = __builtin_elementwise_fma(sg, db.zw, da.zw);
+                }
             }
             wg_v2 vl[4], vh[4];
             vl[0] = tl[0] - tl[2]; vh[0] = th[0] - th[2];
