@@ -273,10 +273,10 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ch = u / MT, mt = u % MT;
-            if (mt == 0) load_u(st * CPS + ch + NB - 1, bq[(ch + NB - 1) % NB]);
+            // Global loads are issued from INSIDE the unit's MFMA block (after 4 resp. 12 of its MFMAs), never in front
+            // of it: in front they cost ~20 % of the matrix rate at two waves per SIMD (tools/micro/vs_loop.hip).
             // vmcnt retires in order: the next stage's patch loads (HBM latency) must be YOUNGER than every U
-            // fragment load that is consumed inside this stage, or each such wait would also wait for the patch
-            if (u == (NB - 2) * MT && more) stage_load((st + 1) * KS);
+            // fragment load that is consumed inside this stage, or each such wait would also wait for the patch.
             // V = B^T d B for the wave's row xi: packed fp32 math, 16 VALU instructions per unit.  The raw rows of
             // unit u+1 (same stage buffer) are read right after unit u's transform has consumed the registers, i.e.
             // BEFORE unit u's MFMAs: the LDS latency hides behind them (matters at one wave per SIMD).
@@ -309,7 +309,15 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
             vl[3] = tl[1] - tl[3]; vh[3] = th[1] - th[3];
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int nu = 0; nu < 4; ++nu)
+            for (int nu = 0; nu < 4; ++nu) {
+                if (nu == 1 && mt == 0) {
+                    load_u(st * CPS + ch + NB - 1, bq[(ch + NB - 1) % NB]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (nu == 3 && u == (NB - 2) * MT && more) {
+                    stage_load((st + 1) * KS);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float4 bb = bq[ch % NB][nt][nu];
@@ -318,6 +326,7 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
                     acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.z, vh[nu].x, acc[mt][nt][nu], 0, 0, 0);
                     acc[mt][nt][nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.w, vh[nu].y, acc[mt][nt][nu], 0, 0, 0);
                 }
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (more) stage_store(smem + ((st + 1) & 1) * Geo::STAGE);
@@ -342,6 +351,7 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
 // Each VMEM instruction costs ~23 cycles and each VALU 4 cycles of matrix-pipe time (tools/micro/wino_loop.hip),
 // so this removes most of the non-MFMA issue slots.  LDS: 51 KB patch, re-used as the reduction buffer.
 #define WGV_C 64
+#define WGV_LOAD_AT 2                                    // U loads after 8 of a chunk's 16 MFMAs
 #define WGV_CGS (WGV_C / 4)
 #define WGV_F4 (10 * WG_PW * WGV_CGS)                       // 2880 float4
 #define WGV_SLOTS ((WGV_F4 + IG_THREADS - 1) / IG_THREADS)  // 12
@@ -439,11 +449,16 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
         for (int kc = 0; kc < WGV_C / 8; ++kc) {
             ++lin;
             const float* un = up + (size_t)(lin < nlin ? lin : nlin - 1) * 1024;      // next chunk (next tile's first after the 8th)
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) bq[(kc + 1) & 1][nu] = ig_ldg4(un + nu * 256);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
+                // the next chunk's U loads go out in the MIDDLE of this chunk's MFMA block: issued in front of it they
+                // cost 20 % of the matrix rate at two waves per SIMD, after 8 of the 16 MFMAs nothing (tools/micro/vs_loop.hip)
+                if (nu == WGV_LOAD_AT) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[(kc + 1) & 1][q] = ig_ldg4(un + q * 256);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const float4 bb = bq[kc & 1][nu];
                 acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.x, vl[kc][nu].x, acc[nu], 0, 0, 0);
                 acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.y, vl[kc][nu].y, acc[nu], 0, 0, 0);
@@ -514,16 +529,16 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
                     (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
     if (!ok) return -1;
     const int ntiles = (a.Cout + 31) / 32;
-    // variant = MT*10 + NT (tuning / tests); 0 = auto.  Measured on MI355X (tools/bench_conv.py, B = 16): the 16x16-pixel
-    // block (MT = 2) wins while it still gives every CU >= 2 blocks; below that the 64-channel block (NT = 2), and for
-    // a single 32-channel tile (DCN offset convs) the small block keeps the most CUs busy; in between, the
-    // 16x16-pixel x 64-channel block (MT = NT = 2, one wave per SIMD with 512 VGPRs) is 3-8 % ahead.
+    // variant = MT*10 + NT (tuning / tests); 0 = auto.  Measured on MI355X (tools/bench_conv.py, B = 16): the 8x16-pixel x
+    // 64-channel block (NT = 2: every V fragment feeds two MFMAs) is the best general shape; for 512..2047 such blocks
+    // the 16x16-pixel x 64-channel block (MT = NT = 2, one wave per SIMD with 512 VGPRs) is 3-8 % ahead; a single
+    // 32-channel tile (DCN offset convs) takes the small block, which keeps the most CUs busy.
     if (variant == 0) {
         const long long blocks21 = (long long)a.B * cp_cdiv(a.H, 16) * cp_cdiv(a.W, WG_TW) * ntiles;
         const long long blocks_vs = (long long)a.B * cp_cdiv(a.H, 8) * cp_cdiv(a.W, WG_TW);
         // 64 input channels and >= 4 channel tiles (the head convs): V-stationary kernel, one block per spatial tile
         if (a.srcC[0] == 64 && ntiles >= 4 && blocks_vs >= 512) variant = 6401;
-        else variant = ntiles == 1 ? 11 : (blocks21 >= 2048 ? 21 : (blocks21 >= 512 && ntiles % 2 == 0 ? 22 : 12));
+        else variant = ntiles == 1 ? 11 : (blocks21 >= 512 && blocks21 < 2048 && ntiles % 2 == 0 ? 22 : 12);
     }
     // 64xx: V-stationary kernel (C == 64), xx = number of channel-tile groups per spatial tile (0 -> 1)
     if (variant >= 6400 && variant < 6500) return a.srcC[0] == 64 ? launch_wino_vs64(a, s, variant - 6400) : -1;

@@ -5,7 +5,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-template <int MODE, int PRIO, int SKEW>
+template <int MODE, int PRIO, int SKEW, int LATE>
 __global__ __launch_bounds__(256, 2) void k(float* out, const float* __restrict__ u, int tiles)
 {
     __shared__ __attribute__((aligned(16))) float lds[16384];
@@ -36,6 +36,10 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* __restrict_
                     tmp[n] = *(const __attribute__((address_space(1))) v4f*)((const char*)ub_ + n * 1024 + vo);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) bq[(kc + 1) & 1][n] = tmp[n];
+            } else if (MODE == 6) {     // non-temporal loads (bypass L1)
+                const float* un = up + (lin & 63) * 1024;
+#pragma unroll
+                for (int n = 0; n < 4; ++n) bq[(kc + 1) & 1][n] = __builtin_nontemporal_load((const __attribute__((address_space(1))) v4f*)(un + n * 256));
             } else if (MODE == 4) {     // same bytes as 8 x dwordx2
                 const float* un = up + (lin & 63) * 1024 - lane * 2;
                 typedef float v2f __attribute__((ext_vector_type(2)));
@@ -49,6 +53,8 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* __restrict_
                 const float* un = lds + ((lin & 3) * 4096 + lane * 4) % 12288;
 #pragma unroll
                 for (int n = 0; n < 4; ++n) bq[(kc + 1) & 1][n] = *(const v4f*)(un + n * 256);
+            } else if (MODE == 2 && LATE > 0) {
+                // loads are issued inside the MFMA block below
             } else if (MODE >= 1) {
                 const float* un = up + (lin & 63) * 1024;
                 v4f tmp[4];
@@ -65,6 +71,12 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* __restrict_
             if (PRIO) __builtin_amdgcn_s_setprio(PRIO);
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
+                if (MODE == 2 && LATE > 0 && n == LATE) {
+                    const float* un = up + (lin & 63) * 1024;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bq[(kc + 1) & 1][q] = *(const __attribute__((address_space(1))) v4f*)(un + q * 256);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 const v4f bb = bq[MODE >= 2 ? (kc & 1) : 0][n];
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.x, V[kc][n].x, acc[n], 0, 0, 0);
                 acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.y, V[kc][n].y, acc[n], 0, 0, 0);
@@ -79,14 +91,14 @@ __global__ __launch_bounds__(256, 2) void k(float* out, const float* __restrict_
     out[blockIdx.x * 256 + tid] = s;
 }
 
-template <int MODE, int PRIO = 0, int SKEW = 0> void run(const char* name, int blocks_per_cu, const float* u)
+template <int MODE, int PRIO = 0, int SKEW = 0, int LATE = 0> void run(const char* name, int blocks_per_cu, const float* u)
 {
     float* out; hipMalloc(&out, 256 * 8 * 256 * 4 * sizeof(float));
     const int tiles = 400, grid = 256 * blocks_per_cu;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    k<MODE, PRIO, SKEW><<<grid, 256>>>(out, u, 10);
+    k<MODE, PRIO, SKEW, LATE><<<grid, 256>>>(out, u, 10);
     hipEventRecord(e0);
-    k<MODE, PRIO, SKEW><<<grid, 256>>>(out, u, tiles);
+    k<MODE, PRIO, SKEW, LATE><<<grid, 256>>>(out, u, tiles);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)grid * 4 * tiles * 128 * 2.0 * 32 * 32 * 2;
@@ -106,7 +118,11 @@ int main()
         run<2, 0, 256>("U double-buffered, wave bases skewed 1 KB", bpc, u);
         run<3>("U via saddr + 32-bit voffset", bpc, u);
         run<4>("U via 8 x dwordx2", bpc, u);
+        run<2, 0, 0, 1>("U loads issued after 4 MFMAs", bpc, u);
+        run<2, 0, 0, 2>("U loads issued after 8 MFMAs", bpc, u);
+        run<2, 0, 0, 3>("U loads issued after 12 MFMAs", bpc, u);
         run<5>("U via 4 x ds_read_b128", bpc, u);
+        run<6>("U via nontemporal loads", bpc, u);
     }
     return 0;
 }
