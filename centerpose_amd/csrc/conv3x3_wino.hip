@@ -265,6 +265,7 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
         }
     };
     constexpr bool PIPE = MT * NT >= 4;       // one wave per SIMD: nobody else hides the LDS round trip
+    constexpr bool STORE_IN_BLOCK = U >= 2;   // patch hand-over (ds_write) from inside the last unit's MFMA block
     const int nstage = C / KS;
 #pragma unroll 1
     for (int st = 0; st < nstage; ++st) {
@@ -318,6 +319,10 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
                     stage_load((st + 1) * KS);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                if (STORE_IN_BLOCK && nu == 2 && u == U - 1 && more) {      // the other stage buffer: nobody reads it now
+                    stage_store(smem + ((st + 1) & 1) * Geo::STAGE);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float4 bb = bq[ch % NB][nt][nu];
@@ -329,7 +334,7 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) stage_store(smem + ((st + 1) & 1) * Geo::STAGE);
+        if (!STORE_IN_BLOCK && more) stage_store(smem + ((st + 1) & 1) * Geo::STAGE);
         __syncthreads();
     }
 
@@ -530,15 +535,14 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
     if (!ok) return -1;
     const int ntiles = (a.Cout + 31) / 32;
     // variant = MT*10 + NT (tuning / tests); 0 = auto.  Measured on MI355X (tools/bench_conv.py, B = 16): the 8x16-pixel x
-    // 64-channel block (NT = 2: every V fragment feeds two MFMAs) is the best general shape; for 512..2047 such blocks
-    // the 16x16-pixel x 64-channel block (MT = NT = 2, one wave per SIMD with 512 VGPRs) is 3-8 % ahead; a single
-    // 32-channel tile (DCN offset convs) takes the small block, which keeps the most CUs busy.
+    // 64-channel block (NT = 2: every V fragment feeds two MFMAs) is the best general shape on every DLA-34 / ResNet-50
+    // layer; a single 32-channel tile (DCN offset convs) takes the 32-channel block.  The larger shapes (21, 22, 41)
+    // stay selectable: they were ahead before the global loads moved inside the MFMA blocks.
     if (variant == 0) {
-        const long long blocks21 = (long long)a.B * cp_cdiv(a.H, 16) * cp_cdiv(a.W, WG_TW) * ntiles;
         const long long blocks_vs = (long long)a.B * cp_cdiv(a.H, 8) * cp_cdiv(a.W, WG_TW);
         // 64 input channels and >= 4 channel tiles (the head convs): V-stationary kernel, one block per spatial tile
         if (a.srcC[0] == 64 && ntiles >= 4 && blocks_vs >= 512) variant = 6401;
-        else variant = ntiles == 1 ? 11 : (blocks21 >= 512 && blocks21 < 2048 && ntiles % 2 == 0 ? 22 : 12);
+        else variant = ntiles == 1 ? 11 : 12;
     }
     // 64xx: V-stationary kernel (C == 64), xx = number of channel-tile groups per spatial tile (0 -> 1)
     if (variant >= 6400 && variant < 6500) return a.srcC[0] == 64 ? launch_wino_vs64(a, s, variant - 6400) : -1;

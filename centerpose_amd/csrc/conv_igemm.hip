@@ -103,8 +103,9 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         int cur = 0;
         for (int ks = 0; ks < nk; ++ks) {
             const bool more = ks + 1 < nk;
-            if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
-            ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc);
+            ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
+                if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
+            });
             // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
             // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
             __builtin_amdgcn_sched_barrier(0);

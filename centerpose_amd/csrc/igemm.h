@@ -137,9 +137,12 @@ __device__ __forceinline__ void ig_store_b(float* Bs, int tid, const float4 (&br
 }
 
 // ---- MFMA over one k-step held in LDS --------------------------------------------------------
-template <class T, int MF>
+// `mid` is called once after half of the k-step's MFMAs have been issued: the place for the next slice's global loads.
+// Issued in FRONT of an MFMA block they cost up to 20 % of the matrix rate at two waves per SIMD, from inside it nothing
+// (tools/micro/vs_loop.hip).
+template <class T, int MF, class F>
 __device__ __forceinline__ void ig_compute(const float* As, const float* Bs, int wm0, int wn0, int lane,
-                                           typename IgAcc<MF>::type (&acc)[T::TM][T::TN])
+                                           typename IgAcc<MF>::type (&acc)[T::TM][T::TN], F&& mid)
 {
     constexpr int G = 64 / MF;           // k-groups across the wave: 2 (32x32x2) or 4 (16x16x4)
     constexpr int NH = IG_BK / (4 * G);  // b128 reads per operand row per k-step: 2 or 1
@@ -154,18 +157,32 @@ __device__ __forceinline__ void ig_compute(const float* As, const float* Bs, int
         for (int j = 0; j < T::TN; ++j)
             bf[h][j] = *reinterpret_cast<const float4*>(Bs + (wn0 + j * MF + il) * IG_LDK + h * 4 * G + g * 4);
     }
+    constexpr int HALF = NH * T::TM * T::TN / 2;       // (h, i, j) tiles before the hook
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int h = 0; h < NH; ++h) {
 #pragma unroll
         for (int i = 0; i < T::TM; ++i)
 #pragma unroll
             for (int j = 0; j < T::TN; ++j) {
+                if ((h * T::TM + i) * T::TN + j == HALF) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    mid();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 acc[i][j] = ig_mfma<MF>(af[h][i].x, bf[h][j].x, acc[i][j]);
                 acc[i][j] = ig_mfma<MF>(af[h][i].y, bf[h][j].y, acc[i][j]);
                 acc[i][j] = ig_mfma<MF>(af[h][i].z, bf[h][j].z, acc[i][j]);
                 acc[i][j] = ig_mfma<MF>(af[h][i].w, bf[h][j].w, acc[i][j]);
             }
     }
+}
+
+template <class T, int MF>
+__device__ __forceinline__ void ig_compute(const float* As, const float* Bs, int wm0, int wn0, int lane,
+                                           typename IgAcc<MF>::type (&acc)[T::TM][T::TN])
+{
+    ig_compute<T, MF>(As, Bs, wm0, wn0, lane, acc, [] {});
 }
 
 __device__ __forceinline__ float ig_act(float v, int act)
