@@ -19,16 +19,24 @@
 #define DCN_MAX_TAPS 9
 typedef float dcn_v2 __attribute__((ext_vector_type(2)));
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MF>
+// KW = 16-deep k-steps gathered at once.  KW = 2: a (pixel, corner) gather covers 32 channels = one whole 128-byte
+// cache line (8 lanes x 16 B) instead of a 64-byte half: PMC shows 71 % of the gather's line accesses miss the 32 KB L1
+// and go to L2 (5 blocks per CU thrash it), and L2 -> L1 moves 128-byte lines, so half-line gathers waste half of the
+// fabric bandwidth this kernel is bound by (tools/micro/l1_gather.hip: 19 vs 32 TB/s useful for 64 B vs 128 B segments).
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, int KW>
 __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs a)
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
+    constexpr int QL = 4 * KW;                      // lanes (float4 quads) per pixel
+    constexpr int PPP = IG_THREADS / QL;            // pixels per pass
+    constexpr int ASL = BM / PPP;                   // gather slots per thread per step
+    static_assert(ASL >= 1, "BM too small for this gather width");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // records first, GEMM staging after; the NCHW epilogue reuses the whole region from the base
     float4* s_w = reinterpret_cast<float4*>(smem);                 // [taps][BM] corner weights * mask
     int* s_code = reinterpret_cast<int*>(s_w + DCN_MAX_TAPS * BM); // [taps][BM] base | dx<<29 | dy<<30
-    float* As0 = smem + DCN_MAX_TAPS * BM * 5;
-    float* Bs0 = As0 + 2 * T::A_FLOATS;
+    float* As0 = smem + DCN_MAX_TAPS * BM * 5;      // [2 buffers][KW][A_FLOATS]
+    float* Bs0 = As0 + 2 * KW * T::A_FLOATS;        // [2 buffers][KW][B_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int NT = a.ldw / BN;
@@ -87,17 +95,17 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < IgAcc<MF>::N; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.K / IG_BK;
-    const int q = tid & 3;
-    float4 br[T::B_SLOTS];
-    float4 c00[T::A_SLOTS], c01[T::A_SLOTS], c10[T::A_SLOTS], c11[T::A_SLOTS], wq[T::A_SLOTS];
+    const int nk = a.K / (IG_BK * KW);
+    const int q = tid % QL;
+    float4 br[KW][T::B_SLOTS];
+    float4 c00[ASL], c01[ASL], c10[ASL], c11[ASL], wq[ASL];
     int tap = 0, cl = 0;
     __syncthreads();
 
     auto load_a = [&]() __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < T::A_SLOTS; ++s) {
-            const int pl = (tid >> 2) + s * 64;
+        for (int s = 0; s < ASL; ++s) {
+            const int pl = tid / QL + s * PPP;
             const int code = s_code[tap * BM + pl];
             wq[s] = s_w[tap * BM + pl];
             const int base = code & 0x1FFFFFFF, dx = (code >> 29) & 1, dy = (code >> 30) & 1;
@@ -108,11 +116,11 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
             c11[s] = *reinterpret_cast<const float4*>(p0 + (size_t)dy * a.W * ld + dx * ld);
         }
     };
-    auto advance = [&]() __attribute__((always_inline)) { cl += IG_BK; if (cl >= C) { cl = 0; ++tap; } };
+    auto advance = [&]() __attribute__((always_inline)) { cl += IG_BK * KW; if (cl >= C) { cl = 0; ++tap; } };
     auto store_a = [&](float* As) __attribute__((always_inline)) {
 #pragma unroll
-        for (int s = 0; s < T::A_SLOTS; ++s) {
-            const int pl = (tid >> 2) + s * 64;
+        for (int s = 0; s < ASL; ++s) {
+            const int pl = tid / QL + s * PPP;
             // packed fp32 (v_pk_mul / v_pk_fma, weight broadcast through op_sel): 8 VALU instructions per float4
             // instead of 16 -- every VALU instruction costs ~4 cycles of matrix-pipe time (tools/micro/wino_loop.hip)
             const float4 w = wq[s];
@@ -123,27 +131,44 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
             const dcn_v2 hi = __builtin_elementwise_fma(ww, (dcn_v2){c11[s].z, c11[s].w},
                               __builtin_elementwise_fma(wz, (dcn_v2){c10[s].z, c10[s].w},
                               __builtin_elementwise_fma(wy, (dcn_v2){c01[s].z, c01[s].w}, wx * (dcn_v2){c00[s].z, c00[s].w})));
-            *reinterpret_cast<float4*>(As + pl * IG_LDK + q * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+            *reinterpret_cast<float4*>(As + (q >> 2) * T::A_FLOATS + pl * IG_LDK + (q & 3) * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
     };
 
+    auto load_b = [&](int ks) __attribute__((always_inline)) {
+#pragma unroll
+        for (int w = 0; w < KW; ++w) ig_load_b<T>(a, (ks * KW + w) * IG_BK, n0, tid, br[w]);
+    };
+    auto store_b = [&](float* Bs) __attribute__((always_inline)) {
+#pragma unroll
+        for (int w = 0; w < KW; ++w) ig_store_b<T>(Bs + w * T::B_FLOATS, tid, br[w]);
+    };
     load_a(); advance();
-    ig_load_b<T>(a, 0, n0, tid, br);
+    load_b(0);
     store_a(As0);
-    ig_store_b<T>(Bs0, tid, br);
+    store_b(Bs0);
     __syncthreads();
     int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
         const bool more = ks + 1 < nk;
-        ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
-            if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
-        });
+        const float* Ac = As0 + cur * KW * T::A_FLOATS;
+        const float* Bc = Bs0 + cur * KW * T::B_FLOATS;
+        auto prefetch = [&]() __attribute__((always_inline)) { if (more) { load_a(); advance(); load_b(ks + 1); } };
+        // the next step's gathers are issued from inside the MFMA block (between the two k-steps, or half-way through one)
+        if constexpr (KW == 1) ig_compute<T, MF>(Ac, Bc, wm0, wn0, lane, acc, prefetch);
+        else {
+            ig_compute<T, MF>(Ac, Bc, wm0, wn0, lane, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            prefetch();
+            __builtin_amdgcn_sched_barrier(0);
+            ig_compute<T, MF>(Ac + T::A_FLOATS, Bc + T::B_FLOATS, wm0, wn0, lane, acc);
+        }
         // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
         // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
         __builtin_amdgcn_sched_barrier(0);
         if (more) {
-            store_a(As0 + (cur ^ 1) * T::A_FLOATS);
-            ig_store_b<T>(Bs0 + (cur ^ 1) * T::B_FLOATS, tid, br);
+            store_a(As0 + (cur ^ 1) * KW * T::A_FLOATS);
+            store_b(Bs0 + (cur ^ 1) * KW * T::B_FLOATS);
         }
         __syncthreads();
         cur ^= 1;
@@ -151,13 +176,14 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MF>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, int KW = 1>
 static int launch_dcn(const ConvArgs& a, hipStream_t s)
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
-    auto kern = dcn_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MF>;
+    auto kern = dcn_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MF, KW>;
+    if (a.srcC[0] % (IG_BK * KW) != 0) { cp_set_error("dcn: C=%d is not a multiple of %d", a.srcC[0], IG_BK * KW); return 1; }
     if (a.ldw % BN != 0) { cp_set_error("dcn: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
-    const int main_bytes = T::MAIN_BYTES + DCN_MAX_TAPS * BM * 20;
+    const int main_bytes = KW * T::MAIN_BYTES + DCN_MAX_TAPS * BM * 20;
     const int epi = a.outNCHW ? T::EPI_BYTES : T::EPV_BYTES;
     const int smem = epi > main_bytes ? epi : main_bytes;
     static bool attr = false;
@@ -214,6 +240,8 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
         case 64064: rc = launch_dcn<64, 64, 2, 2, 32>(a, s); break;
         case 128128: rc = launch_dcn<128, 128, 2, 2, 32>(a, s); break;
         case 64128: rc = launch_dcn<64, 128, 2, 2, 32>(a, s); break;
+        case 2064064: rc = launch_dcn<64, 64, 2, 2, 32, 2>(a, s); break;      // 32-channel (full cache line) gathers
+        case 2128064: rc = launch_dcn<128, 64, 2, 2, 32, 2>(a, s); break;
         default: CP_CHECK_ARG(false, "dcn_v2: unsupported tile %d (ldw=%d)", tile, d->ldw);
     }
     if (rc) return rc;
