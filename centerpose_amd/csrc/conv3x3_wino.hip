@@ -6,25 +6,26 @@
 //     Y = A^T [ sum_c (G g G^T) .* (B^T d B) ] A         (Lavin & Gray; B, G, A have entries 0, +-1, +-1/2)
 // i.e. 16 independent GEMMs  M[xi][nu][tile][n] = sum_c V[xi][nu][tile][c] * U[xi][nu][n][c].
 // Everything is fused in one kernel; nothing of the Winograd domain touches HBM:
-//   * block = 8x16 output pixels = 4x8 Winograd tiles = ONE 32-row MFMA tile, times 32*NT output channels;
+//   * block = 8*MT x 16 output pixels = MT sets of 4x8 Winograd tiles (one 32-wide MFMA tile each), times 32*NT output
+//     channels; (MT,NT) = (1,2) is the general shape, (1,1) for a single channel tile;
 //   * wave xi (0..3) owns transform row xi: the four frequencies (xi, nu=0..3).  Row xi of B^T has two
 //     non-zeros, so the wave needs only two of the four rows of every 4x4 input tile;
 //   * the raw (8+2)x(16+2) input patch is staged in LDS 16 channels at a time (double buffered, one
 //     barrier per stage).  A lane (tile m, k-half h) reads 8 ds_read_b128 (2 rows x 4 cols x 4 channels),
-//     forms V with 32 VALU adds and feeds it STRAIGHT into the MFMA A operand - V never exists in memory;
+//     forms V with 16 packed-fp32 ops and feeds it STRAIGHT into the MFMA operand registers - V never exists in memory;
 //   * U (transformed weights, cp_winograd_pack_f32) is wave-private (each wave has its own frequencies),
-//     so its B fragments go global -> registers as coalesced 1 KiB wave loads, prefetched one 8-channel
-//     chunk ahead; no LDS, no barrier;
+//     so its fragments go global -> registers as coalesced 1 KiB wave loads, prefetched one 8-channel chunk ahead
+//     and issued from INSIDE the MFMA block (in front of it they cost up to 20 % of the matrix rate); no LDS, no barrier;
 //   * per 8-channel chunk and wave: 8 ds_read_b128 + 16 packed VALU + 4*NT global loads feed 16*NT
 //     v_mfma_f32_32x32x2f32 (64 cycles each).  Measured on MI355X (tools/micro/wino_loop.hip): every VALU
 //     instruction costs ~4 cycles of matrix-pipe time (no co-issue, same or other wave), so the transform and
 //     the epilogue use v_pk_{add,fma}_f32 and block-index math is scalar (host-side magic division);
-//   * epilogue: the nu-sum of A is done in registers, the xi-sum across the four waves through LDS, then
-//     scale/shift (folded BN) + residual + activation and float4 NHWC stores.
+//   * the MFMA is issued as D[channel][tile] (A = U fragment, B = V fragment) so a lane ends up with 4 consecutive
+//     channels; epilogue: the nu-sum of A is done in registers, the xi-sum across the four waves through LDS
+//     (ds_write_b128), then scale/shift (folded BN) + residual + activation and float4 NHWC stores.
 // Arithmetic is fp32 throughout; the result differs from the direct convolution by ordinary fp32
 // rounding (~1e-6 relative, measured in tests/test_conv_hip.py), far inside the path's 1e-3 bar.
 #include "igemm.h"
-#include <cstdlib>
 
 #define WG_TW 16
 #define WG_PW (WG_TW + 2)
@@ -353,8 +354,9 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
 // block (whole 64-channel halo patch staged in LDS in one go), then the block loops over its output-channel tiles
 // with an inner loop that is nothing but U-fragment loads and MFMAs - no LDS reads, no transform VALU, no barrier,
 // no patch re-staging per channel tile (the generic kernel re-stages the patch for each of the 8 tiles of a head).
-// Each VMEM instruction costs ~23 cycles and each VALU 4 cycles of matrix-pipe time (tools/micro/wino_loop.hip),
-// so this removes most of the non-MFMA issue slots.  LDS: 51 KB patch, re-used as the reduction buffer.
+// Every VALU instruction costs ~4 cycles of matrix-pipe time and global loads issued in front of an MFMA block up to 20 %
+// of the matrix rate (tools/micro/wino_loop.hip, vs_loop.hip), so this removes most of the non-MFMA issue slots.
+// LDS: 51 KB patch, re-used as two 37 KB reduction buffers.
 #define WGV_C 64
 #define WGV_LOAD_AT 2                                    // U loads after 8 of a chunk's 16 MFMAs
 #define WGV_CGS (WGV_C / 4)
@@ -484,7 +486,7 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
 {
     auto kern = conv3x3_wino_kernel<MT, NT, KS, NB>;
     using Geo = WgGeo<MT, KS>;
-    const int smem = getenv("CP_WG_SMEM") ? atoi(getenv("CP_WG_SMEM")) : Geo::SMEM_FLOATS * 4;
+    const int smem = Geo::SMEM_FLOATS * 4;
     if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
         cp_set_error("conv3x3_winograd: cannot reserve %d B LDS", smem);
         return 2;
@@ -503,7 +505,7 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
 
 static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups)
 {
-    const int smem = getenv("CP_VS_SMEM") ? atoi(getenv("CP_VS_SMEM")) : WGV_SMEM_FLOATS * 4;
+    const int smem = WGV_SMEM_FLOATS * 4;
     static bool attr = false;
     if (!attr) {
         hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_vs64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
