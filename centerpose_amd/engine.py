@@ -225,6 +225,18 @@ class Engine:
         self.graph = None
         self.use_graph = use_graph
 
+    # -- on-disk plan --------------------------------------------------------------
+    def save_plan(self, path):
+        """Write the compiled plan (packed weights + launch schedule) so a later start skips checkpoint parsing,
+        BN folding and weight packing: `Engine.from_plan(path)`."""
+        from . import plan
+        return plan.save_plan(self, path)
+
+    @classmethod
+    def from_plan(cls, path, device="cuda", use_graph=True):
+        from . import plan
+        return plan.load_plan(path, device=device, use_graph=use_graph)
+
     # -- execution ------------------------------------------------------------------------------
     def run_eager(self):
         for _, _, _, fn in self.launches:

@@ -133,6 +133,27 @@ def test_engine_determinism():
     assert all(torch.equal(p, q) for p, q in zip(a, b))
 
 
+@pytest.mark.parametrize("arch", ARCHS)
+def test_plan_roundtrip(arch, tmp_path):
+    """On-disk plan: save the compiled plan, reload it without checkpoint / packing, same bits out,
+    eagerly and through a captured hipGraph."""
+    from centerpose_amd import engine, synth
+    x = synth.make_images(2, 128, 128).cuda()
+    eng = engine.Engine(arch, synth.make_state_dict(arch), 2, 128, 128, use_graph=False)
+    ref = [t.clone() for t in eng(x)]
+    path = str(tmp_path / "plan.pt")
+    eng.save_plan(path)
+    assert all(torch.equal(p, q) for p, q in zip(ref, eng(x)))          # recording did not disturb the engine
+    del eng
+    for use_graph in (False, True):
+        e2 = engine.Engine.from_plan(path, use_graph=use_graph)
+        assert (e2.arch, e2.B, e2.H, e2.W) == (engine.nets.canonical_arch(arch), 2, 128, 128)
+        out = e2(x)
+        torch.cuda.synchronize()
+        assert len(out) == 6 and all(torch.equal(p, q) for p, q in zip(ref, out))
+        assert len(e2.profile(iters=1)) == len(e2.launches)
+
+
 def test_device_preprocess_matches_host_restatement():
     """cp_preprocess_u8_f32 (warp + normalise + HWC->CHW + mirrored twin) vs the numpy float restatement."""
     from centerpose_amd import config, detector

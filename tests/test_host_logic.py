@@ -139,3 +139,34 @@ def test_flip_helpers_roundtrip():
     hps = r.randn(1, 34, 8, 8).astype(np.float32)
     assert np.array_equal(decode_np.flip_lr(decode_np.flip_lr(hp)), hp)
     assert np.array_equal(decode_np.flip_lr_off(decode_np.flip_lr_off(hps)), hps)
+
+
+def test_plan_format_encode_decode_and_schema(tmp_path):
+    """Plan file helpers on CPU tensors: buffer views (offset / stride) and constants survive encode -> torch.save ->
+    decode; schema errors are reported."""
+    from centerpose_amd import plan
+    buf = torch.arange(4 * 6 * 8, dtype=torch.float32).reshape(4, 6, 8)
+    view = buf[1:3, :, 2:6]                                  # strided view into a written storage
+    const = torch.randn(5, 7)
+    enc = plan._Encoder({buf.untyped_storage().data_ptr()})
+    args = {"srcs": [view, buf], "wp": const, "out": buf, "pad_yx": (1, 0), "res": None, "relu": True}
+    enc_args = {k: enc.value(v) for k, v in args.items()}
+    assert enc_args["srcs"][0][:3] == ("buf", 0, 8 * 6 + 2) and enc_args["wp"] == ("const", 0) and enc_args["pad_yx"] == [1, 0]
+    p = {"format": plan.FORMAT, "version": plan.VERSION, "meta": {"arch": "x", "abi": 1}, "input": enc.view(buf), "outputs": [],
+         "buffers": enc.buf_numel, "consts": enc.consts, "ops": [{"kind": "conv", "name": "n", "flops": 1, "fn": "conv2d", "args": enc_args}]}
+    f = str(tmp_path / "p.pt")
+    torch.save(p, f)
+    q = torch.load(f, weights_only=False)
+    assert plan.check_plan(q) == {"arch": "x", "abi": 1}
+    dec = plan._Decoder(q, "cpu")
+    dec.bufs[0].copy_(buf.reshape(-1))
+    got = {k: dec.value(v) for k, v in q["ops"][0]["args"].items()}
+    assert torch.equal(got["srcs"][0], view) and got["srcs"][0].stride() == view.stride()
+    assert torch.equal(got["wp"], const) and got["pad_yx"] == [1, 0] and got["res"] is None and got["relu"] is True
+    with pytest.raises(ValueError):
+        plan.check_plan({"format": "other"})
+    with pytest.raises(ValueError):
+        plan.check_plan(dict(q, version=99))
+    bad = dict(q, ops=[dict(q["ops"][0], fn="not_a_launch")])
+    with pytest.raises(ValueError):
+        plan.check_plan(bad)
