@@ -58,14 +58,6 @@ def _storage_key(t):
     return t.untyped_storage().data_ptr()
 
 
-def _tensors_of(v):
-    if isinstance(v, torch.Tensor):
-        yield v
-    elif isinstance(v, (list, tuple)):
-        for x in v:
-            yield from _tensors_of(x)
-
-
 class _Encoder:
     """tensor -> view handle; buffers are the storages some launch writes (plus the network input)."""
 
