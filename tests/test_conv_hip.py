@@ -291,6 +291,40 @@ def test_conv3x3_winograd_kernel(cin, cout, hw, B, nt):
         assert torch.isnan(buf[..., cout:]).all()      # nothing stored past Cout
 
 
+def test_conv3x3_winograd_fuzz_vs_direct_kernel():
+    """Seeded random shapes (odd H/W, batch 1..3, ragged channel tiles, strided input / output / residual views, every
+    activation, every block shape): the Winograd kernel against the direct halo-patch kernel on the same buffers."""
+    from centerpose_amd import ops
+    rng = np.random.RandomState(5)
+    g = torch.Generator().manual_seed(5)
+    variants = [0, 11, 12, 21, 22, 41]
+    for it in range(14):
+        B = int(rng.randint(1, 4))
+        H, W = int(rng.randint(3, 41)), int(rng.randint(3, 45))
+        cin = int(rng.choice([32, 48, 64, 96]))
+        cout = int(rng.choice([16, 27, 32, 40, 64, 100, 128]))
+        act = int(rng.choice([ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SIGMOID]))
+        var = 6400 + int(rng.randint(0, 3)) if (cin == 64 and it % 3 == 0) else int(variants[it % len(variants)])
+        in_ld, out_ld = cin + 16 * int(rng.randint(0, 2)), ops.round_up(cout, 4) + 4 * int(rng.randint(0, 3))
+        xb = torch.randn(B, H, W, in_ld, generator=g).cuda()
+        x = xb[..., in_ld - cin:]                                         # channel-offset view
+        w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+        wp = ops.pack_conv_weight(w)
+        u = ops.pack_wino_weight(wp, cin, cout)
+        sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in _rand_bn(g, cout)))
+        use_res = bool(rng.randint(0, 2))
+        resb = torch.randn(B, H, W, out_ld, generator=g).cuda() if use_res else None
+        res = resb[..., :cout] if use_res else None
+        outs = []
+        for wino in (None, u):
+            ob = torch.full((B, H, W, out_ld), float("nan"), device="cuda")
+            ops.conv2d([x], wp, sc, sh, ob[..., :cout], kh=3, kw=3, stride=1, pad=1, cout=cout, act=act, res=res,
+                       tile=var if wino is not None else 0, wino=wino)
+            assert torch.isnan(ob[..., cout:]).all(), "case %d wrote past Cout" % it
+            outs.append(ob[..., :cout])
+        _close(outs[1], outs[0], 1e-4)
+
+
 @pytest.mark.parametrize("cout,s,hw", [(16, 1, (40, 72)), (64, 2, (37, 70)), (16, 1, (512, 512)), (64, 2, (128, 96))])
 def test_stem7x7_kernel(cout, s, hw):
     """dedicated 7x7 stem (pose_dla_dcn.py:228-232 / msra_resnet.py:118-121) vs torch-CPU."""
