@@ -54,8 +54,8 @@ int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w
                   const float* res, float* out, void* stream);
 
 /* ---- 3x3 / stride 1 / pad 1 convolution as fused Winograd F(2x2,3x3) ---------------------------------
- * Same layers and epilogue as cp_conv2d_f32 (the reference gets these from cuDNN, which also picks Winograd
- * for fp32 3x3 under cudnn.benchmark = True, lib/detectors/base_detector.py / main.py); 16 multiplies per
+ * Same layers and epilogue as cp_conv2d_f32 (the reference gets these from cuDNN, which chooses the algorithm itself --
+ * heuristics, or autotuned with CUDNN.BENCHMARK, lib/config/default.py:29, tools/train.py:32); 16 multiplies per
  * 2x2 output tile and (cin, cout) instead of 36, fp32 throughout (error ~3e-6 relative, below the direct kernel's).
  * cp_winograd_pack_f32: packed direct weights w [rows >= Cout][9*C] (k = (ky*3+kx)*C + c, as for cp_conv2d_f32)
  *   -> u [cp_winograd_weight_floats(C, Cout)] = G g G^T in the kernel's MFMA B-fragment order; C % 16 == 0.
