@@ -118,12 +118,16 @@ def main():
         achieved = mm_flops / (mm_ms * 1e-3) / 1e12
         # Winograd F(2x2,3x3) launches execute 16/36 of their algorithmic (direct-convolution) multiply-adds
         exe_flops = sum(r["flops"] * (16.0 / 36.0 if r["kind"] == "wino" else 1.0) for r in mm)
+        # per-launch min-bound: a launch cannot finish before max(flop / MFMA peak, compulsory bytes / HBM bandwidth)
+        bound_ms = sum(max(r["flops"] / (PEAK_F32_MFMA_TFLOPS * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9)) for r in mm) * 1e3
         roof = {"bound": "mfma", "kernel": "conv3x3_wino_kernel / igemm_conv_kernel / dcn_igemm_kernel (fp32 MFMA)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                 "executed_mfma_tflops": round(exe_flops / (mm_ms * 1e-3) / 1e12, 2),
                 "executed_frac": round(exe_flops / (mm_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
                 "winograd_launches": sum(1 for r in mm if r["kind"] == "wino"),
+                "min_bound_frac": round(bound_ms / mm_ms, 4),
+                "algorithmic_mb_per_step": round(sum(r["bytes"] for r in mm) / 1e6, 1),
                 "launches_per_step": len(mm), "gemm_ms_per_step": round(mm_ms, 3),
                 "all_kernels_ms_per_step": round(all_ms, 3),
                 "algorithmic_gflop_per_image": round(eng.flops_per_image / 1e9, 2),

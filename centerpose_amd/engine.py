@@ -272,17 +272,39 @@ class Engine:
 
     __call__ = forward
 
+    def launch_bytes(self):
+        """Algorithmic (compulsory) HBM bytes of every launch: each tensor argument once - inputs, residual, the weights
+        the kernel actually reads, output.  Taken from the recorded launch arguments (plan._Recorder), so it follows
+        whatever the plan builder emitted."""
+        from . import plan
+        out = []
+        with torch.cuda.device(self.device):
+            for kind, _, _, fn in self.launches:
+                with plan._Recorder() as rec:
+                    fn()
+                n = 0
+                for _, args in rec.calls:
+                    for key, v in args.items():
+                        if (key == "wp" and args.get("wino") is not None) or v is None:
+                            continue                      # Winograd launches read U, not the direct weights
+                        ts = v if isinstance(v, (list, tuple)) else [v]
+                        n += sum(4 * t.numel() for t in ts if isinstance(t, torch.Tensor))
+                out.append(n)
+            torch.cuda.synchronize(self.device)
+        return out
+
     def profile(self, iters=5):
-        """Per-launch timing with HIP events on the launch stream -> list of dicts."""
+        """Per-launch timing with HIP events on the launch stream -> list of dicts (kind, name, flops, bytes, ms)."""
         torch.cuda.synchronize(self.device)
         self.run_eager()
+        nbytes = self.launch_bytes()
         recs = []
-        for kind, name, flops, fn in self.launches:
+        for (kind, name, flops, fn), nb in zip(self.launches, nbytes):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
                 fn()
             e1.record()
             e1.synchronize()
-            recs.append(dict(kind=kind, name=name, flops=flops, ms=e0.elapsed_time(e1) / iters))
+            recs.append(dict(kind=kind, name=name, flops=flops, bytes=nb, ms=e0.elapsed_time(e1) / iters))
         return recs

@@ -12,4 +12,6 @@ recs = eng.profile(iters=10)
 tot = sum(r["ms"] for r in recs)
 print("%s B=%d: %d launches, %.3f ms total, %.1f img/s, %.1f TF overall" % (arch, B, len(recs), tot, B / tot * 1e3, sum(r["flops"] for r in recs) / tot / 1e9))
 for r in recs:
-    print("%-5s %-62s %8.3f ms %7.1f GF %6.1f TF  %4.1f%%" % (r["kind"], r["name"][-62:], r["ms"], r["flops"] / 1e9, r["flops"] / r["ms"] / 1e9 if r["ms"] else 0, 100 * r["ms"] / tot))
+    print("%-5s %-62s %8.3f ms %7.1f GF %6.1f TF  %4.1f%%  %7.1f MB %5.2f TB/s" % (
+        r["kind"], r["name"][-62:], r["ms"], r["flops"] / 1e9, r["flops"] / r["ms"] / 1e9 if r["ms"] else 0, 100 * r["ms"] / tot,
+        r["bytes"] / 1e6, r["bytes"] / r["ms"] / 1e9 if r["ms"] else 0))
