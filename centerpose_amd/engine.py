@@ -292,6 +292,7 @@ class Engine:
         fork = torch.cuda.Event()
         fork.record(main)
         joined = [True] + [False] * (len(streams) - 1)
+        waited = [[-1] * len(streams) for _ in streams]      # waited[s][t]: youngest launch of stream t that s has waited for
         for i, (_, _, _, fn) in enumerate(self.launches):
             # continue the chain of a predecessor that is still the tail of its stream; otherwise take an idle stream
             sidx = None
@@ -306,9 +307,16 @@ class Engine:
             if not joined[sidx]:
                 st.wait_event(fork)
                 joined[sidx] = True
+            # streams are FIFO: per source stream only the youngest predecessor matters, and only if this stream has
+            # not already waited for it (or a younger one)
+            need = {}
             for j in deps[i]:
                 if where[j] != sidx:
+                    need[where[j]] = max(need.get(where[j], -1), j)
+            for t, j in need.items():
+                if j > waited[sidx][t]:
                     st.wait_event(events[j])
+                    waited[sidx][t] = j
             with torch.cuda.stream(st):
                 fn()
             ev = torch.cuda.Event()
