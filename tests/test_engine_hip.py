@@ -177,6 +177,35 @@ def test_multistream_capture_is_bit_identical(arch):
         assert all(torch.equal(p, q) for p, q in zip(outs[0], o))
 
 
+def test_full_size_batch_invariance_and_scaling_property():
+    """Size-independent properties at BASELINE's full 512x512 size (the oracle is too slow there): (1) an image's head
+    maps do not depend on which batch it travels in - B=4 in one engine == the same images through a B=2 engine, bit for
+    bit (different grids, same per-output arithmetic); (2) one Winograd layer is exactly homogeneous under power-of-two
+    scaling of its input (every step is a sum of products)."""
+    from centerpose_amd import engine, ops, synth
+    sd = synth.make_state_dict("dla_34")
+    x = synth.make_images(4).cuda()
+    e4 = engine.Engine("dla_34", sd, 4, 512, 512)
+    full = [t.clone() for t in e4(x)]
+    del e4
+    e2 = engine.Engine("dla_34", sd, 2, 512, 512)
+    for half in range(2):
+        part = e2(x[2 * half:2 * half + 2])
+        torch.cuda.synchronize()
+        assert all(torch.equal(f[2 * half:2 * half + 2], p) for f, p in zip(full, part))
+    g = torch.Generator().manual_seed(3)
+    xin = torch.randn(16, 128, 128, 64, generator=g).cuda()
+    w = (torch.randn(256, 64, 3, 3, generator=g) / 24.0).cuda()
+    wp = ops.pack_conv_weight(w)
+    u = ops.pack_wino_weight(wp, 64, 256)
+    sc, sh = torch.ones(256, device="cuda"), torch.zeros(256, device="cuda")
+    o1, o2 = torch.empty(16, 128, 128, 256, device="cuda"), torch.empty(16, 128, 128, 256, device="cuda")
+    ops.conv2d([xin], wp, sc, sh, o1, kh=3, kw=3, stride=1, pad=1, cout=256, wino=u)
+    ops.conv2d([xin * 4.0], wp, sc, sh, o2, kh=3, kw=3, stride=1, pad=1, cout=256, wino=u)
+    torch.cuda.synchronize()
+    assert torch.equal(o1 * 4.0, o2)
+
+
 def test_device_preprocess_matches_host_restatement():
     """cp_preprocess_u8_f32 (warp + normalise + HWC->CHW + mirrored twin) vs the numpy float restatement."""
     from centerpose_amd import config, detector
