@@ -150,6 +150,20 @@ def main():
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
                            "weights": "seeded synthetic checkpoint (reference key layout)"},
                 "roofline": roof}
+        # ---- decode alone (latency-bound; reported as us/batch next to its HBM GB/s) ------------------
+        hm, wh, hps, reg, hm_hp, hp_offset = eng.outputs
+        for _ in range(3):
+            multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset, K=100)
+        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        d0.record()
+        for _ in range(20):
+            multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset, K=100)
+        d1.record()
+        d1.synchronize()
+        dec_us = d0.elapsed_time(d1) / 20 * 1e3
+        dec_bytes = B * (18 * hm.shape[2] * hm.shape[3] * 4 + 28800 + 22400)     # hm + hm_hp maps, gathers, dets
+        line["decode"] = {"us_per_batch": round(dec_us, 1), "algorithmic_bytes": dec_bytes,
+                          "gbps": round(dec_bytes / dec_us / 1e3, 1), "kernels": "nms_topk_kernel + pose_assign_kernel"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch)
         print(json.dumps(line), flush=True)
