@@ -487,9 +487,13 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
     auto kern = conv3x3_wino_kernel<MT, NT, KS, NB>;
     using Geo = WgGeo<MT, KS>;
     const int smem = Geo::SMEM_FLOATS * 4;
-    if (smem > 64 * 1024 && hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
-        cp_set_error("conv3x3_winograd: cannot reserve %d B LDS", smem);
-        return 2;
+    static bool attr = false;          // once per instantiation, on the first (warm-up) launch: not legal inside a stream capture
+    if (!attr && smem > 64 * 1024) {
+        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
+            cp_set_error("conv3x3_winograd: cannot reserve %d B LDS", smem);
+            return 2;
+        }
+        attr = true;
     }
     WgGrid gd;
     gd.tilesX = cp_cdiv(a.W, WG_TW); gd.tilesY = cp_cdiv(a.H, Geo::TH);
@@ -533,6 +537,7 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
     const bool ok = a.nsrc == 1 && a.kh == 3 && a.kw == 3 && a.sy == 1 && a.sx == 1 && a.py == 1 && a.px == 1 &&
                     !a.outNCHW && a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Ho == a.H && a.Wo == a.W &&
                     a.OH == a.H && a.OW == a.W && a.srcC[0] % 16 == 0 && a.srcLd[0] % 4 == 0 &&
+                    (((size_t)a.src[0] | (size_t)a.w) & 15) == 0 &&            // 16-byte vector loads of the patch and of U
                     (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
     if (!ok) return -1;
     const int ntiles = (a.Cout + 31) / 32;
