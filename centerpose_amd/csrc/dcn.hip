@@ -102,18 +102,31 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     int tap = 0, cl = 0;
     __syncthreads();
 
+    // Corner byte offsets and blend weights are per (tap, pixel): computed at the first k-step of a tap and reused by its
+    // C/16 k-steps - the channel offset of the step goes into the (scalar) base address, so the steady state issues the
+    // four gathers with no address VALU at all (every VALU instruction costs ~4 cycles of matrix-pipe time).
+    const unsigned pixb = (unsigned)ld * 4u, rowb = (unsigned)a.W * pixb;
+    unsigned o00[ASL], o01[ASL], o10[ASL], o11[ASL];
     auto load_a = [&]() __attribute__((always_inline)) {
+        if (cl == 0) {
+#pragma unroll
+            for (int s = 0; s < ASL; ++s) {
+                const int pl = tid / QL + s * PPP;
+                const int code = s_code[tap * BM + pl];
+                wq[s] = s_w[tap * BM + pl];
+                o00[s] = (unsigned)(code & 0x1FFFFFFF) * pixb + (unsigned)q * 16u;
+                o01[s] = o00[s] + (((unsigned)code >> 29) & 1u) * pixb;
+                o10[s] = o00[s] + (((unsigned)code >> 30) & 1u) * rowb;
+                o11[s] = o10[s] + (o01[s] - o00[s]);
+            }
+        }
+        const char* xs = reinterpret_cast<const char*>(x) + (size_t)cl * 4;      // uniform
 #pragma unroll
         for (int s = 0; s < ASL; ++s) {
-            const int pl = tid / QL + s * PPP;
-            const int code = s_code[tap * BM + pl];
-            wq[s] = s_w[tap * BM + pl];
-            const int base = code & 0x1FFFFFFF, dx = (code >> 29) & 1, dy = (code >> 30) & 1;
-            const float* p0 = x + (size_t)base * ld + cl + q * 4;
-            c00[s] = *reinterpret_cast<const float4*>(p0);
-            c01[s] = *reinterpret_cast<const float4*>(p0 + dx * ld);
-            c10[s] = *reinterpret_cast<const float4*>(p0 + (size_t)dy * a.W * ld);
-            c11[s] = *reinterpret_cast<const float4*>(p0 + (size_t)dy * a.W * ld + dx * ld);
+            c00[s] = ig_ldg4(reinterpret_cast<const float*>(xs + o00[s]));
+            c01[s] = ig_ldg4(reinterpret_cast<const float*>(xs + o01[s]));
+            c10[s] = ig_ldg4(reinterpret_cast<const float*>(xs + o10[s]));
+            c11[s] = ig_ldg4(reinterpret_cast<const float*>(xs + o11[s]));
         }
     };
     auto advance = [&]() __attribute__((always_inline)) { cl += IG_BK * KW; if (cl >= C) { cl = 0; ++tap; } };
@@ -215,7 +228,8 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
     CP_CHECK_ARG(d->K == d->kh * d->kw * d->C, "dcn_v2: K=%d != kh*kw*C", d->K);
     CP_CHECK_ARG(d->ldw % 16 == 0 && d->ldw >= d->Cout, "dcn_v2: ldw=%d Cout=%d", d->ldw, d->Cout);
     CP_CHECK_ARG(d->omLd >= 3 * d->kh * d->kw, "dcn_v2: omLd=%d too small", d->omLd);
-    CP_CHECK_ARG((long long)d->B * d->H * d->W < (1ll << 29), "dcn_v2: input too large");
+    CP_CHECK_ARG((long long)d->B * d->H * d->W < (1ll << 29) && (long long)d->B * d->H * d->W * d->srcLd * 4 < (1ll << 32),
+                 "dcn_v2: input too large (pixel index 29 bits, byte offsets 32 bits)");
     ConvArgs a;
     for (int i = 0; i < IG_MAX_SRC; ++i) { a.src[i] = nullptr; a.srcC[i] = 0; a.srcLd[i] = 0; }
     a.src[0] = x; a.srcC[0] = d->C; a.srcLd[0] = d->srcLd; a.nsrc = 1; a.Ctot = d->C;
