@@ -68,16 +68,25 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         // a.src[si] in the loop costs 3 dependent scalar loads + s_waitcnt lgkmcnt(0) per k-step
         const float* sp = a.src[0];
         int ld = a.srcLd[0], sC = a.srcC[0];
+        // Per-slot byte offset and validity depend on (tap, source) only: computed at the first k-step of each segment
+        // (cl == 0) and reused by its C/16 k-steps; the channel offset rides in the scalar base address, so the steady
+        // state issues its gathers with no address VALU (for 1x1 layers that is the whole loop).
+        unsigned aoff[T::A_SLOTS];
         auto load_a = [&]() __attribute__((always_inline)) {
+            if (cl == 0) {
 #pragma unroll
-            for (int s = 0; s < T::A_SLOTS; ++s) {
-                const int iy = ps[s].iy0 + ky, ix = ps[s].ix0 + kx;
-                const bool ok = ps[s].boff >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                // branch-free: out-of-range taps read the (always valid) tensor base and are zeroed
-                const size_t off = ok ? (size_t)(ps[s].boff + iy * a.W + ix) * ld + cl + q * 4 : 0;
-                ar[s] = ig_ldg4(sp + off);            // raw; zeroed at store time (a select here would wait on vmcnt)
-                aok[s] = ok;
+                for (int s = 0; s < T::A_SLOTS; ++s) {
+                    const int iy = ps[s].iy0 + ky, ix = ps[s].ix0 + kx;
+                    const bool ok = ps[s].boff >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+                    // branch-free: out-of-range taps read the (always valid) tensor base and are zeroed at store time
+                    aoff[s] = ok ? ((unsigned)(ps[s].boff + iy * a.W + ix) * (unsigned)ld + (unsigned)q * 4u) * 4u : 0u;
+                    aok[s] = ok;
+                }
             }
+            const char* xs = reinterpret_cast<const char*>(sp) + (size_t)cl * 4;      // uniform
+#pragma unroll
+            for (int s = 0; s < T::A_SLOTS; ++s)
+                ar[s] = ig_ldg4(reinterpret_cast<const float*>(xs + aoff[s]));      // raw; a select here would wait on vmcnt
         };
         auto advance = [&]() __attribute__((always_inline)) {
             cl += IG_BK;
@@ -240,6 +249,8 @@ static int conv_args_from_desc(const cp_conv_desc* d, const float* const* src, c
     a.outNCHW = d->outNCHW; a.OH = d->OH; a.OW = d->OW; a.osy = d->osy; a.osx = d->osx; a.ooy = d->ooy; a.oox = d->oox;
     a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1;
     CP_CHECK_ARG(a.M > 0 && (long long)d->B * d->H * d->W < (1ll << 31), "conv2d: bad problem size");
+    for (int i = 0; i < d->nsrc && !d->inNCHW; ++i)
+        CP_CHECK_ARG((long long)d->B * d->H * d->W * d->srcLd[i] * 4 < (1ll << 32), "conv2d: source %d exceeds 32-bit byte offsets", i);
     CP_CHECK_ARG(!(res && d->outNCHW), "conv2d: residual with NCHW output is not supported");
     return 0;
 }
