@@ -342,14 +342,22 @@ class Engine:
         # chain-like DLA-34 / ResNet-50 graphs.  (Three or more streams crash hipStreamEndCapture on ROCm 7.2 for the DLA /
         # HRNet graphs - not for ResNet-50 or a minimal reproducer - so the default stays at two.)
         nstreams = getattr(self, "nstreams", None) or int(os.environ.get("CP_STREAMS", "2"))
-        g = torch.cuda.CUDAGraph()
+        g = None
         if nstreams > 1:
             deps = self.dependencies()           # runs every launch once: must happen outside the capture
-            with torch.cuda.graph(g, stream=s):
-                self._run_branches(s, nstreams, deps)
-        else:
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, stream=s):
+                    self._run_branches(s, nstreams, deps)
+            except RuntimeError:                 # a failed multi-stream capture must not take the engine down
+                g = None
+                self._capture_refs = None
+                torch.cuda.synchronize(self.device)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.run_eager()
+            self.stream_of_launch = [0] * len(self.launches)
         self.graph = g
 
     def forward(self, images):
