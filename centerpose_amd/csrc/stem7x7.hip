@@ -59,7 +59,7 @@ __global__ __launch_bounds__(IG_THREADS) void stem7x7_kernel(const float* __rest
     const int g = lane >> 4, il = lane & 15;
     // lane's A base inside a (c,ky) patch row: column of pixel il plus its 4-wide kx group
     const int a_col = il * S + (g & 1) * 4;
-#pragma unroll 1
+#pragma unroll          // 11 steps, fully unrolled: (c, ky) of a step and the row offsets become compile-time constants per k-half
     for (int st = 0; st < S7_STEPS; ++st) {
         const int row = 2 * st + (g >> 1);           // (c*7 + ky); row 21 (last half-step) has zero weights
         const int c = row / 7, ky = row - c * 7;
