@@ -26,8 +26,19 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
     float* Bs0 = smem + 2 * T::A_FLOATS;     // [2][BN][IG_LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    int tile = ig_xcd_remap(blockIdx.x, gridDim.x);
+    // per-block view of the fields that differ between the sub-convolutions of a fused sub-pixel deconvolution (nsub = 4):
+    // a 2048 -> 256 deconv at 16x16 is 4 x 128 blocks with 512 k-steps each - half the CUs idle per launch when run one by one
+    const float* wsub = a.w;
+    int pys = a.py, pxs = a.px, ooys = 0, ooxs = 0;
+    if (a.nsub > 1) {
+        const int per = gridDim.x / a.nsub, sub = tile / per;
+        tile -= sub * per;
+        wsub += (size_t)sub * a.ldw * a.K;
+        pys -= sub >> 1; pxs -= sub & 1;
+        ooys = sub >> 1; ooxs = sub & 1;
+    }
     const int NT = a.ldw / BN;
-    const int tile = ig_xcd_remap(blockIdx.x, gridDim.x);
     const int nt = tile % NT, mt = tile / NT;
     const int m0 = mt * BM, n0 = nt * BN;
     const int wm0 = (wid / WAVES_N) * T::WM, wn0 = (wid % WAVES_N) * T::WN;
@@ -54,8 +65,8 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
             if (m < a.M) {
                 const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
                 ps[s].boff = b * a.H * a.W;
-                ps[s].iy0 = oy * a.sy - a.py;
-                ps[s].ix0 = ox * a.sx - a.px;
+                ps[s].iy0 = oy * a.sy - pys;
+                ps[s].ix0 = ox * a.sx - pxs;
             } else { ps[s].boff = -1; ps[s].iy0 = 0; ps[s].ix0 = 0; }
         }
         float4 ar[T::A_SLOTS];
@@ -105,7 +116,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         };
 
         load_a(); advance();
-        ig_load_b<T>(a, 0, n0, tid, br);
+        ig_load_b<T>(a, 0, n0, tid, br, wsub);
         store_a(As0);
         ig_store_b<T>(Bs0, tid, br);
         __syncthreads();
@@ -113,7 +124,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         for (int ks = 0; ks < nk; ++ks) {
             const bool more = ks + 1 < nk;
             ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
-                if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
+                if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br, wsub); }
             });
             // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
             // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
@@ -179,7 +190,7 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
             cur ^= 1;
         }
     }
-    ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc);
+    ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc, ooys, ooxs);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, bool STEM>
@@ -194,7 +205,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s)
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM > T::NHWC_BYTES ? T::SMEM : T::NHWC_BYTES);
         attr = true;
     }
-    const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN);
+    const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN) * (a.nsub > 1 ? a.nsub : 1);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
     return 0;
 }
@@ -216,6 +227,7 @@ struct cp_conv_desc {
     int act;
     int inNCHW;   // 1: src[0] is the NCHW network input with srcC[0] (<16) channels (stem path)
     int tile;     // 0 = auto; otherwise BM*1000+BN of a specific instantiation (tuning / tests)
+    int nsub;     // 0 / 1: one conv; 4: fused sub-pixel deconvolution (see ConvArgs::nsub)
 };
 
 static int conv_args_from_desc(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale,
@@ -247,7 +259,7 @@ static int conv_args_from_desc(const cp_conv_desc* d, const float* const* src, c
     a.K = d->K; a.w = w; a.ldw = d->ldw; a.scale = scale; a.shift = shift;
     a.res = res; a.resLd = d->resLd; a.out = out; a.outLd = d->outLd; a.Cout = d->Cout;
     a.outNCHW = d->outNCHW; a.OH = d->OH; a.OW = d->OW; a.osy = d->osy; a.osx = d->osx; a.ooy = d->ooy; a.oox = d->oox;
-    a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1;
+    a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1; a.nsub = d->nsub > 1 ? d->nsub : 1;
     CP_CHECK_ARG(a.M > 0 && (long long)d->B * d->H * d->W < (1ll << 31), "conv2d: bad problem size");
     for (int i = 0; i < d->nsrc && !d->inNCHW; ++i)
         CP_CHECK_ARG((long long)d->B * d->H * d->W * d->srcLd[i] * 4 < (1ll << 32), "conv2d: source %d exceeds 32-bit byte offsets", i);
@@ -263,7 +275,12 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
     hipStream_t s = (hipStream_t)stream;
 
     int tile = d->tile;
-    if (tile == 0 || tile == 3 || tile == 332) {   // 3x3/s1/p1 NHWC: LDS-resident halo patch kernel (conv3x3_patch.hip)
+    if (a.nsub > 1) {
+        CP_CHECK_ARG(a.nsub == 4 && !d->inNCHW && d->osy == 2 && d->osx == 2 && d->ooy == 0 && d->oox == 0 && d->kh == 2 && d->kw == 2,
+                     "conv2d: nsub=4 is the fused k4/s2/p1 deconvolution (2x2 taps, output stride 2)");
+        CP_CHECK_ARG(tile == 0 || tile > 1000, "conv2d: nsub needs the generic kernel");
+    }
+    if (a.nsub == 1 && (tile == 0 || tile == 3 || tile == 332)) {   // 3x3/s1/p1 NHWC: LDS-resident halo patch kernel (conv3x3_patch.hip)
         const int prc = cp_launch_conv3x3_patch(a, d->inNCHW, s, tile == 332 ? 32 : 0);
         if (prc >= 0) {
             if (prc) return prc;

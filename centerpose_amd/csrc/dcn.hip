@@ -239,7 +239,7 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
     a.out = out; a.outLd = d->outLd; a.Cout = d->Cout; a.outNCHW = d->outNCHW;
     a.OH = d->Ho; a.OW = d->Wo; a.osy = a.osx = 1; a.ooy = a.oox = 0; a.act = d->act;
     a.om = om; a.omLd = d->omLd; a.omMaskOff = 2 * d->kh * d->kw; a.omSigmoid = d->omSigmoid;
-    a.dily = d->dily; a.dilx = d->dilx;
+    a.dily = d->dily; a.dilx = d->dilx; a.nsub = 1;
     hipStream_t s = (hipStream_t)stream;
     int tile = d->tile;
     if (tile == 0) {

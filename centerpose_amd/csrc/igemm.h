@@ -56,6 +56,8 @@ struct ConvArgs {
     int omMaskOff;            // first mask channel (2*kh*kw)
     int omSigmoid;            // 1: mask channel holds logits (apply sigmoid), 0: mask given directly
     int dily, dilx;           // dilation (DCNv2 drop-in only; plain convs are dilation 1)
+    int nsub;                 // 1, or 4: the four sub-pixel 2x2 convs of a k4/s2/p1 ConvTranspose2d in ONE launch (generic kernel only):
+                              // sub g = py*2+px uses weights w + g*ldw*K, pad (py0 - py, px0 - px) and output phase (ooy + py, oox + px)
 };
 
 // conv3x3_patch.hip: returns -1 when the shape is not eligible, else 0 / error code
@@ -118,12 +120,13 @@ struct IgTile {
 
 // ---- B (weights) slice: global [n][K] -> regs -> LDS Bs[n][k] --------------------------------
 template <class T>
-__device__ __forceinline__ void ig_load_b(const ConvArgs& a, int k0, int n0, int tid, float4 (&br)[T::B_SLOTS])
+__device__ __forceinline__ void ig_load_b(const ConvArgs& a, int k0, int n0, int tid, float4 (&br)[T::B_SLOTS], const float* w = nullptr)
 {
+    if (!w) w = a.w;
 #pragma unroll
     for (int s = 0; s < T::B_SLOTS; ++s) {
         const int idx = tid + s * IG_THREADS;
-        if (idx < T::B_F4) br[s] = *reinterpret_cast<const float4*>(a.w + (size_t)(n0 + (idx >> 2)) * a.K + k0 + (idx & 3) * 4);
+        if (idx < T::B_F4) br[s] = *reinterpret_cast<const float4*>(w + (size_t)(n0 + (idx >> 2)) * a.K + k0 + (idx & 3) * 4);
     }
 }
 template <class T>
@@ -195,9 +198,11 @@ __device__ __forceinline__ float ig_act(float v, int act)
 // ---- epilogue --------------------------------------------------------------------------------
 template <class T, int BM, int BN, int MF>
 __device__ __forceinline__ void ig_epilogue(const ConvArgs& a, float* smem, int m0, int n0, int wm0, int wn0,
-                                            int lane, int tid, typename IgAcc<MF>::type (&acc)[T::TM][T::TN])
+                                            int lane, int tid, typename IgAcc<MF>::type (&acc)[T::TM][T::TN],
+                                            int ooy_add = 0, int oox_add = 0)      // extra output phase (fused sub-pixel deconv)
 {
     const int HoWo = a.Ho * a.Wo;
+    const int ooy = a.ooy + ooy_add, oox = a.oox + oox_add;
     const int cl = lane & (MF - 1);
     const bool vec_ok = !a.outNCHW && ((a.outLd | a.Cout) & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
                         (!a.res || ((a.resLd & 3) == 0 && (((size_t)a.res) & 15) == 0));
@@ -205,7 +210,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvArgs& a, float* smem, int 
         // NHWC, vectorised: the C tile goes through LDS (Cs[m][n]) so that every thread handles float4
         // runs along n: 16-byte residual loads and stores instead of 4-byte ones (4x fewer VMEM
         // instructions; memory-bound 1x1 layers are epilogue-dominated)
-        const bool dense = (a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.OH == a.Ho && a.OW == a.Wo);
+        const bool dense = (a.osy == 1 && a.osx == 1 && ooy == 0 && oox == 0 && a.OH == a.Ho && a.OW == a.Wo);
         const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
         float* Cs = smem;
         constexpr int LDC = BN + 4;
@@ -228,7 +233,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvArgs& a, float* smem, int 
                 size_t opix = (size_t)m;
                 if (!dense) {
                     const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
-                    opix = ((size_t)b * a.OH + (oy * a.osy + a.ooy)) * a.OW + (ox * a.osx + a.oox);
+                    opix = ((size_t)b * a.OH + (oy * a.osy + ooy)) * a.OW + (ox * a.osx + oox);
                 }
                 float4 v = *reinterpret_cast<const float4*>(Cs + row * LDC + c4 * 4);
                 const float4 sc = *reinterpret_cast<const float4*>(a.scale + n);
@@ -247,7 +252,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvArgs& a, float* smem, int 
             }
         }
     } else if (!a.outNCHW) {
-        const bool dense = (a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.OH == a.Ho && a.OW == a.Wo);
+        const bool dense = (a.osy == 1 && a.osx == 1 && ooy == 0 && oox == 0 && a.OH == a.Ho && a.OW == a.Wo);
         const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
 #pragma unroll
         for (int i = 0; i < T::TM; ++i) {
@@ -258,7 +263,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvArgs& a, float* smem, int 
                 size_t opix = (size_t)m;
                 if (!dense) {
                     const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
-                    opix = ((size_t)b * a.OH + (oy * a.osy + a.ooy)) * a.OW + (ox * a.osx + a.oox);
+                    opix = ((size_t)b * a.OH + (oy * a.osy + ooy)) * a.OW + (ox * a.osx + oox);
                 }
                 float* orow = a.out + opix * a.outLd;
                 const float* rrow = a.res ? a.res + opix * a.resLd : nullptr;
@@ -296,7 +301,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvArgs& a, float* smem, int 
             const int m = m0 + ml, n = n0 + nl;
             if (m < a.M && n < a.Cout) {
                 const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
-                a.out[(((size_t)b * a.Cout + n) * a.OH + (oy * a.osy + a.ooy)) * a.OW + (ox * a.osx + a.oox)] =
+                a.out[(((size_t)b * a.Cout + n) * a.OH + (oy * a.osy + ooy)) * a.OW + (ox * a.osx + oox)] =
                     Cs[nl * LDC + ml];
             }
         }

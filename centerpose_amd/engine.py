@@ -130,14 +130,14 @@ class PlanBuilder(nets.Graph):
         w = self.w(wname + ".weight")
         sc, sh = ops.fold_bn(co, self.bn(bn), None, self.dev)
         xt, ot, H, W = x.t, out.t, x.H, x.W
-        for py in range(2):
-            for px in range(2):
-                wp = ops.pack_deconv4_subpixel(w, py, px)
+        # the four sub-pixel 2x2 convolutions in ONE launch (sub g = py*2+px): 4x the blocks - a 2048 -> 256 deconv at
+        # 16x16 is otherwise 4 x 128 blocks of 512 k-steps each on 256 CUs
+        wp = torch.cat([ops.pack_deconv4_subpixel(w, py, px) for py in range(2) for px in range(2)], 0).contiguous()
 
-                def fn(wp=wp, py=py, px=px):
-                    ops.conv2d([xt], wp, sc, sh, ot, kh=2, kw=2, stride=1, pad=0, pad_yx=(1 - py, 1 - px), cout=co,
-                               act=ops.ACT_RELU, Ho=H, Wo=W, out_scatter=(2, 2, py, px))
-                self.add("conv", "%s[%d%d]" % (wname, py, px), 2 * H * W * co * x.C * 4, fn)
+        def fn():
+            ops.conv2d([xt], wp, sc, sh, ot, kh=2, kw=2, stride=1, pad=0, pad_yx=(1, 1), cout=co, act=ops.ACT_RELU, Ho=H, Wo=W,
+                       out_scatter=(2, 2, 0, 0), nsub=4)
+        self.add("conv", wname, 4 * 2 * H * W * co * x.C * 4, fn)
         return out
 
     def emit_sum_up(self, xs, shifts, relu):

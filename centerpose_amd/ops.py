@@ -18,7 +18,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("nsrc",)] + [("srcC", ctypes.c_int * 4), ("srcLd", ctypes.c_int * 4)] + \
         [(n, ctypes.c_int) for n in ("B", "H", "W", "Ho", "Wo", "kh", "kw", "sy", "sx", "py", "px", "K", "ldw", "Cout",
                                      "resLd", "outLd", "outNCHW", "OH", "OW", "osy", "osx", "ooy", "oox", "act",
-                                     "inNCHW", "tile")]
+                                     "inNCHW", "tile", "nsub")]
 
 
 class DcnDesc(ctypes.Structure):
@@ -93,9 +93,11 @@ def _ld(t):
 
 
 def conv2d(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=ACT_NONE, res=None, out_nchw=False,
-           in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0, wino=None):
+           in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0, wino=None, nsub=1):
     """Fused conv: out = act((sum_src conv(src)) * scale + shift [+ res]).
 
+    nsub = 4: the four sub-pixel 2x2 convs of a dense ConvTranspose2d(k4,s2,p1) in one launch; wp = [4*ldw, K] (sub g = py*2+px),
+    pad_yx = (1, 1), out_scatter = (2, 2, 0, 0).
     wino: Winograd-domain weights from `pack_wino_weight` -> the 3x3/s1/p1 launch goes through the fused
     F(2x2,3x3) kernel (cp_conv3x3_winograd_f32); `tile` then selects 32 (1) / 64 (2) channels per block.
 
@@ -121,7 +123,8 @@ def conv2d(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=AC
         Wo = (W + 2 * px - kw) // stride + 1
     d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, Ho, Wo
     d.kh, d.kw, d.sy, d.sx, d.py, d.px = kh, kw, stride, stride, py, px
-    d.K, d.ldw, d.Cout = wp.shape[1], wp.shape[0], cout
+    assert wp.shape[0] % nsub == 0
+    d.K, d.ldw, d.Cout, d.nsub = wp.shape[1], wp.shape[0] // nsub, cout, nsub
     d.resLd = _ld(res) if res is not None else 0
     d.outNCHW = 1 if out_nchw else 0
     if out_nchw:

@@ -49,6 +49,9 @@ typedef struct cp_conv_desc {
     int act;
     int inNCHW;               /* 1: src[0] is the NCHW network input [B,srcC[0],H,W] (base_detector.py:53-58) */
     int tile;                 /* 0 = auto; BM*1000+BN to force a kernel instantiation */
+    int nsub;                 /* 0 / 1: one convolution.  4: the four sub-pixel 2x2 convolutions of a dense ConvTranspose2d(k4,s2,p1)
+                                 (msra_resnet.py:168-193) in ONE launch: w = [4][ldw][K] (sub g = py*2+px), py = px = 1, osy = osx = 2,
+                                 ooy = oox = 0; sub g uses pad (1-py, 1-px) and output phase (py, px) */
 } cp_conv_desc;
 int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale, const float* shift,
                   const float* res, float* out, void* stream);

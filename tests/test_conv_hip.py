@@ -128,6 +128,12 @@ def test_dense_deconv_as_subpixel_convs():
             ops.conv2d([xg], wp, sc, sh, out, kh=2, kw=2, stride=1, pad=0, pad_yx=(1 - py_, 1 - px_), cout=Co,
                        act=ops.ACT_RELU, Ho=H, Wo=W, out_scatter=(2, 2, py_, px_))
     _close(out.permute(0, 3, 1, 2), ref)
+    # the same four convolutions fused into one launch (nsub = 4): bit-identical to the four separate launches
+    out4 = torch.full_like(out, float("nan"))
+    wp4 = torch.cat([ops.pack_deconv4_subpixel(w.cuda(), py_, px_) for py_ in range(2) for px_ in range(2)], 0).contiguous()
+    ops.conv2d([xg], wp4, sc, sh, out4, kh=2, kw=2, stride=1, pad=0, pad_yx=(1, 1), cout=Co, act=ops.ACT_RELU, Ho=H, Wo=W,
+               out_scatter=(2, 2, 0, 0), nsub=4)
+    assert torch.equal(out4, out)
 
 
 @pytest.mark.parametrize("k,s,p", [(2, 2, 0), (3, 2, 1)])
