@@ -347,7 +347,7 @@ class Engine:
             deps = self.dependencies()           # runs every launch once: must happen outside the capture
             try:
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, stream=s):
+                with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                     self._run_branches(s, nstreams, deps)
             except RuntimeError:                 # a failed multi-stream capture must not take the engine down
                 g = None
@@ -355,7 +355,8 @@ class Engine:
                 torch.cuda.synchronize(self.device)
         if g is None:
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: a collective library's watchdog thread (RCCL under torchrun) must not invalidate the capture
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.run_eager()
             self.stream_of_launch = [0] * len(self.launches)
         self.graph = g
