@@ -9,16 +9,36 @@
 #define EW_THREADS 256
 static inline int ew_grid(long long n) { long long g = (n + EW_THREADS - 1) / EW_THREADS; return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g)); }
 
-__global__ void maxpool_nhwc_kernel(const float* __restrict__ in, int inLd, float* __restrict__ out, int outLd, int B,
-                                    int H, int W, int C4, int Ho, int Wo, int k, int s, int p)
+// Row-major launch geometry for the pixel kernels: blockIdx.y walks the (image, output row) pairs, threads walk the
+// (column, channel quad) pairs of one row.  All index math is 32-bit; the one division per element (by the uniform
+// C/4) is a multiply-high with a host-made magic number (exact for e * C4 < 2^32).  The grid-stride 64-bit % and /
+// this replaces cost ~200 instructions per element and made these "bandwidth-bound" helpers ALU-bound.
+struct EwRow { int rows, rowElems, C4; unsigned mC4; };
+static inline EwRow ew_row(int rows, int Wo, int C4)
 {
-    const long long total = (long long)B * Ho * Wo * C4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long long pix = i / C4;
-        const int ox = (int)(pix % Wo); pix /= Wo;
-        const int oy = (int)(pix % Ho);
-        const int b = (int)(pix / Ho);
+    EwRow r; r.rows = rows; r.rowElems = Wo * C4; r.C4 = C4;
+    r.mC4 = C4 <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)C4 - 1) / (unsigned)C4);
+    return r;
+}
+static inline dim3 ew_row_grid(const EwRow& r)
+{
+    return dim3((unsigned)((r.rowElems + EW_THREADS - 1) / EW_THREADS), (unsigned)(r.rows > 65535 ? 65535 : r.rows));
+}
+__device__ __forceinline__ void ew_split(const EwRow& r, int e, int& x, int& c4)
+{
+    x = r.C4 == 1 ? e : (int)__umulhi((unsigned)e, r.mC4);
+    c4 = e - x * r.C4;
+}
+
+__global__ void maxpool_nhwc_kernel(const float* __restrict__ in, int inLd, float* __restrict__ out, int outLd, EwRow r,
+                                    int H, int W, int Ho, int Wo, int k, int s, int p)
+{
+    const int e = blockIdx.x * EW_THREADS + threadIdx.x;
+    if (e >= r.rowElems) return;
+    int ox, c4;
+    ew_split(r, e, ox, c4);
+    for (int row = blockIdx.y; row < r.rows; row += gridDim.y) {
+        const int b = row / Ho, oy = row - b * Ho;                     // uniform
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         for (int ky = 0; ky < k; ++ky) {
             const int iy = oy * s - p + ky;
@@ -30,7 +50,7 @@ __global__ void maxpool_nhwc_kernel(const float* __restrict__ in, int inLd, floa
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
-        *reinterpret_cast<float4*>(out + ((size_t)(b * Ho + oy) * Wo + ox) * outLd + c4 * 4) = m;
+        *reinterpret_cast<float4*>(out + ((size_t)row * Wo + ox) * outLd + c4 * 4) = m;
     }
 }
 
@@ -39,29 +59,30 @@ extern "C" int cp_maxpool2d_nhwc_f32(const float* in, int inLd, float* out, int 
 {
     CP_CHECK_ARG(in && out && C % 4 == 0 && inLd % 4 == 0 && outLd % 4 == 0, "maxpool: C, ld must be multiples of 4");
     const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
-    const long long total = (long long)B * Ho * Wo * (C / 4);
-    hipLaunchKernelGGL(maxpool_nhwc_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, out,
-                       outLd, B, H, W, C / 4, Ho, Wo, k, s, p);
+    CP_CHECK_ARG((long long)Wo * (C / 4) * (C / 4) < (1ll << 32) && (long long)B * Ho < (1ll << 31), "maxpool: row too large");
+    const EwRow r = ew_row(B * Ho, Wo, C / 4);
+    hipLaunchKernelGGL(maxpool_nhwc_kernel, ew_row_grid(r), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, out, outLd, r,
+                       H, W, Ho, Wo, k, s, p);
     CP_CHECK_LAUNCH("maxpool_nhwc_kernel");
     return 0;
 }
 
 // out[b,oy,ox,c] = add[b,oy,ox,c] + sum_{ky,kx} in[b,iy,ix,c] * w[(ky*k+kx)][c],  oy = iy*f - p + ky
 __global__ void dw_deconv_add_kernel(const float* __restrict__ in, int inLd, const float* __restrict__ w,
-                                     const float* __restrict__ add, int addLd, float* __restrict__ out, int outLd, int B,
-                                     int H, int W, int C4, int f, int p)
+                                     const float* __restrict__ add, int addLd, float* __restrict__ out, int outLd, EwRow r,
+                                     int H, int W, int f, int p)
 {
-    const int k = 2 * f, Ho = H * f, Wo = W * f, C = C4 * 4;
-    const long long total = (long long)B * Ho * Wo * C4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long long pix = i / C4;
-        const int ox = (int)(pix % Wo); pix /= Wo;
-        const int oy = (int)(pix % Ho);
-        const int b = (int)(pix / Ho);
+    const int k = 2 * f, Ho = H * f, Wo = W * f, C = r.C4 * 4;
+    const int e = blockIdx.x * EW_THREADS + threadIdx.x;
+    if (e >= r.rowElems) return;
+    int ox, c4;
+    ew_split(r, e, ox, c4);
+    const int rx = (ox + p) % f;
+    for (int row = blockIdx.y; row < r.rows; row += gridDim.y) {
+        const int b = row / Ho, oy = row - b * Ho;                     // uniform
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         // ky = oy + p - iy*f must lie in [0, k): two candidate input rows / columns
-        const int ry = (oy + p) % f, rx = (ox + p) % f;
+        const int ry = (oy + p) % f;
 #pragma unroll
         for (int ty = 0; ty < 2; ++ty) {
             const int ky = ry + ty * f, iy = (oy + p - ky) / f;
@@ -75,10 +96,10 @@ __global__ void dw_deconv_add_kernel(const float* __restrict__ in, int inLd, con
                 acc.x += v.x * ww.x; acc.y += v.y * ww.y; acc.z += v.z * ww.z; acc.w += v.w * ww.w;
             }
         }
-        const size_t opix = (size_t)(b * Ho + oy) * Wo + ox;
+        const size_t opix = (size_t)row * Wo + ox;
         if (add) {
-            const float4 r = *reinterpret_cast<const float4*>(add + opix * addLd + c4 * 4);
-            acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w;
+            const float4 rr = *reinterpret_cast<const float4*>(add + opix * addLd + c4 * 4);
+            acc.x += rr.x; acc.y += rr.y; acc.z += rr.z; acc.w += rr.w;
         }
         *reinterpret_cast<float4*>(out + opix * outLd + c4 * 4) = acc;
     }
@@ -90,24 +111,24 @@ extern "C" int cp_dw_deconv_add_nhwc_f32(const float* in, int inLd, const float*
     CP_CHECK_ARG(in && w && out && C % 4 == 0 && inLd % 4 == 0 && outLd % 4 == 0 && (!add || addLd % 4 == 0),
                  "dw_deconv_add: C, ld must be multiples of 4");
     CP_CHECK_ARG(f >= 1, "dw_deconv_add: f=%d", f);
-    const long long total = (long long)B * H * f * W * f * (C / 4);
-    hipLaunchKernelGGL(dw_deconv_add_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, w, add,
-                       addLd, out, outLd, B, H, W, C / 4, f, f / 2);
+    CP_CHECK_ARG((long long)W * f * (C / 4) * (C / 4) < (1ll << 32) && (long long)B * H * f < (1ll << 31), "dw_deconv_add: row too large");
+    const EwRow r = ew_row(B * H * f, W * f, C / 4);
+    hipLaunchKernelGGL(dw_deconv_add_kernel, ew_row_grid(r), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, w, add,
+                       addLd, out, outLd, r, H, W, f, f / 2);
     CP_CHECK_LAUNCH("dw_deconv_add_kernel");
     return 0;
 }
 
 // out = act( sum_i nearest_up(src_i, 2^sh_i) ), all NHWC with C channels; out is [B,H,W,C]
 struct SumUpArgs { const float* src[4]; int ld[4]; int sh[4]; int n; };
-__global__ void sum_up_kernel(SumUpArgs a, float* __restrict__ out, int outLd, int B, int H, int W, int C4, int relu)
+__global__ void sum_up_kernel(SumUpArgs a, float* __restrict__ out, int outLd, EwRow r, int H, int W, int relu)
 {
-    const long long total = (long long)B * H * W * C4;
-    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        long long pix = i / C4;
-        const int x = (int)(pix % W); pix /= W;
-        const int y = (int)(pix % H);
-        const int b = (int)(pix / H);
+    const int e = blockIdx.x * EW_THREADS + threadIdx.x;
+    if (e >= r.rowElems) return;
+    int x, c4;
+    ew_split(r, e, x, c4);
+    for (int row = blockIdx.y; row < r.rows; row += gridDim.y) {
+        const int b = row / H, y = row - b * H;                        // uniform
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int j = 0; j < a.n; ++j) {
             const int sh = a.sh[j], hs = H >> sh, ws = W >> sh;
@@ -116,7 +137,7 @@ __global__ void sum_up_kernel(SumUpArgs a, float* __restrict__ out, int outLd, i
             else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
         }
         if (relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
-        *reinterpret_cast<float4*>(out + ((size_t)(b * H + y) * W + x) * outLd + c4 * 4) = acc;
+        *reinterpret_cast<float4*>(out + ((size_t)row * W + x) * outLd + c4 * 4) = acc;
     }
 }
 
@@ -127,9 +148,9 @@ extern "C" int cp_sum_up_nhwc_f32(int n, const float* const* src, const int* ld,
     SumUpArgs a;
     for (int i = 0; i < 4; ++i) { a.src[i] = i < n ? src[i] : nullptr; a.ld[i] = i < n ? ld[i] : 0; a.sh[i] = i < n ? shift[i] : 0; }
     a.n = n;
-    const long long total = (long long)B * H * W * (C / 4);
-    hipLaunchKernelGGL(sum_up_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, a, out, outLd, B, H, W,
-                       C / 4, relu);
+    CP_CHECK_ARG((long long)W * (C / 4) * (C / 4) < (1ll << 32) && (long long)B * H < (1ll << 31), "sum_up: row too large");
+    const EwRow r = ew_row(B * H, W, C / 4);
+    hipLaunchKernelGGL(sum_up_kernel, ew_row_grid(r), dim3(EW_THREADS), 0, (hipStream_t)stream, a, out, outLd, r, H, W, relu);
     CP_CHECK_LAUNCH("sum_up_kernel");
     return 0;
 }
