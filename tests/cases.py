@@ -83,4 +83,17 @@ DECODE_CASES = {
     "rand_small": (decode_random, dict(seed=5, B=3, H=32, W=48), 40, True, True),
     "rand_ragged": (decode_random, dict(seed=7, B=1, H=40, W=24, J=5), 17, True, False),
     "people_b2": (decode_people, dict(seed=3, B=2), 100, True, True),
+    # maps above 32768 keys per plane (the multi-block select path): FIX_RES=false inputs, e.g. hrnet_w32_512.yaml
+    # TEST_SCALES [1,2] puts a 640x480 image at scale 2 on a 248x328 map (base_detector.py:42-43)
+    "rand_256": (decode_random, dict(seed=26, B=1, H=256, W=256), 100, True, True),
+    "rand_248x328": (decode_random, dict(seed=29, B=2, H=248, W=328), 100, True, True),
+    "people_248x328": (decode_people, dict(seed=31, B=1, H=248, W=328, n_people=12), 100, True, False),
 }
+
+
+def flip_inputs(seed=41, H=12, W=20, J=17):
+    """Batch of 2 (image, mirrored twin) head outputs for the flip-test merge (multi_pose.py:45-53)."""
+    r = np.random.RandomState(seed)
+    return dict(hm=sigmoid(r.randn(2, 1, H, W)), wh=(r.rand(2, 2, H, W) * 30).astype(F32),
+                hps=(r.randn(2, 2 * J, H, W) * 8).astype(F32), reg=r.rand(2, 2, H, W).astype(F32),
+                hm_hp=sigmoid(r.randn(2, J, H, W) - 1.0), hp_offset=r.rand(2, 2, H, W).astype(F32))

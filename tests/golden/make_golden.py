@@ -40,10 +40,26 @@ def gen_decode():
         print("decode", name, dets.shape, "tie_free", tie_free)
 
 
+def gen_flip():
+    """The reference's flip-test merge (multi_pose.py:45-53 with models/utils.py:27-47) on seeded maps."""
+    from models.utils import flip_lr, flip_lr_off, flip_tensor
+    flip_idx = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]      # multi_pose.py:27
+    t = {k: torch.from_numpy(v) for k, v in cases.flip_inputs().items()}
+    hm = (t["hm"][0:1] + flip_tensor(t["hm"][1:2])) / 2
+    wh = (t["wh"][0:1] + flip_tensor(t["wh"][1:2])) / 2
+    hps = (t["hps"][0:1] + flip_lr_off(t["hps"][1:2], flip_idx)) / 2
+    hm_hp = (t["hm_hp"][0:1] + flip_lr(t["hm_hp"][1:2], flip_idx)) / 2
+    np.savez_compressed(os.path.join(HERE, "flip_merge.npz"), hm=hm.numpy(), wh=wh.numpy(), hps=hps.numpy(),
+                        hm_hp=hm_hp.numpy(), reg=t["reg"][0:1].numpy(), hp_offset=t["hp_offset"][0:1].numpy())
+    print("flip", tuple(hps.shape))
+
+
 if __name__ == "__main__":
-    what = sys.argv[1:] or ["decode", "dcn", "nets"]
+    what = sys.argv[1:] or ["decode", "flip", "dcn", "nets"]
     if "decode" in what:
         gen_decode()
+    if "flip" in what:
+        gen_flip()
     if "dcn" in what or "nets" in what:
         import make_golden_nets
         make_golden_nets.main(what)

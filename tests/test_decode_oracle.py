@@ -53,3 +53,26 @@ def test_oracle_vs_imported_reference(seed):
     out = decode_np.multi_pose_decode(inp["hm"], inp["wh"], inp["hps"], inp["reg"], inp["hm_hp"],
                                       inp["hp_offset"], K=50)
     assert np.array_equal(ref, out)
+
+
+def test_flip_merge_oracle_matches_reference_golden(golden_dir):
+    """decode_np.flip_merge (multi_pose.py:45-53) against the committed outputs of the reference's own
+    flip_tensor / flip_lr / flip_lr_off (models/utils.py:27-47, tests/golden/make_golden.py::gen_flip)."""
+    g = np.load(os.path.join(golden_dir, "flip_merge.npz"))
+    inp = cases.flip_inputs()
+    out = decode_np.flip_merge(inp["hm"], inp["wh"], inp["hps"], inp["reg"], inp["hm_hp"], inp["hp_offset"])
+    for name, o in zip(("hm", "wh", "hps", "reg", "hm_hp", "hp_offset"), out):
+        assert o.dtype == np.float32 and np.array_equal(o, g[name]), name
+
+
+@pytest.mark.reference
+def test_flip_helpers_vs_imported_reference():
+    import torch
+    sys.path.insert(0, "/root/reference/lib")
+    from models.utils import flip_lr, flip_lr_off, flip_tensor
+    r = np.random.RandomState(4)
+    hp = r.randn(2, 17, 6, 10).astype(np.float32)
+    hps = r.randn(2, 34, 6, 10).astype(np.float32)
+    assert np.array_equal(flip_tensor(torch.from_numpy(hp)).numpy(), decode_np.flip_tensor(hp))
+    assert np.array_equal(flip_lr(torch.from_numpy(hp), decode_np.FLIP_IDX).numpy(), decode_np.flip_lr(hp))
+    assert np.array_equal(flip_lr_off(torch.from_numpy(hps), decode_np.FLIP_IDX).numpy(), decode_np.flip_lr_off(hps))
