@@ -2,71 +2,182 @@
 """Throughput bench of the hot path: DLA-34 512x512, images/sec end-to-end (backbone + heads +
 sigmoid + heat-map decode), inputs resident in HBM.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1 directly; N > 1 under torchrun)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a launcher: bench.py re-executes itself under `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1` (one rank per GPU over RCCL); under an external torchrun it reads
+RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
 One "step" = one pass of the hot path over one batch of 16 synthetic images per GPU
 (BASELINE.json configs[2]; at N = 8 this is configs[3]: global batch 128 sharded 16/GPU with an RCCL
-all-gather of the decoded poses).  Prints ONE JSON line on rank 0 with the contract's keys plus
-`roofline` (dominant kernel family: the fp32-MFMA implicit-GEMM convolutions, timed live with HIP
-events on the launch stream) and `cpu_baseline` (the oracle's torch-CPU restatement of the same
-path, timed on this box's host cores on a bounded sample).
+all-gather of the decoded poses, issued on a side stream so it overlaps the next batch's backbone).  Prints ONE JSON line
+on rank 0 with the contract's keys plus
+
+* `roofline`: the DOMINANT kernel of the step by time (kernel families timed live, in sequence, with HIP events on the
+  launch stream): achieved = MFMA FLOPs the kernel executes per second (for a Winograd family 16/36 of the algorithmic
+  direct-convolution count, which is reported next to it), peak = 157.3 TFLOP/s fp32 MFMA; every family's share is listed;
+* `cpu_baseline`: the oracle's torch-CPU restatement of the same path timed on this box's host cores (bounded sample),
+  dla_34 (the metric's workload) plus res_50 B=1 / B=8 split forward / decode (BASELINE.json configs[0]).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
+# C entry point -> device kernel family (names as rocprofv3 --kernel-trace prints them)
+KERNEL_OF = {"cp_dcn_v2_f32": "dcn_igemm_kernel", "cp_conv3x3_winograd_f32": "conv3x3_wino_kernel / conv3x3_wino_vs64_kernel",
+             "cp_conv2d_f32": "igemm_conv_kernel / conv3x3_patch_kernel", "cp_stem7x7_f32": "stem7x7_kernel",
+             "cp_head_fused_f32": "head_fused_kernel",
+             "cp_maxpool2d_nhwc_f32": "maxpool_nhwc_kernel", "cp_dw_deconv_add_nhwc_f32": "dw_deconv_add_kernel",
+             "cp_sum_up_nhwc_f32": "sum_up_kernel"}
+MFMA_FNS = ("cp_dcn_v2_f32", "cp_conv3x3_winograd_f32", "cp_conv2d_f32", "cp_stem7x7_f32", "cp_head_fused_f32")
 
 
-def cpu_baseline(arch, seconds=12.0):
-    """Oracle ("port") on the host cores: forward + sigmoid + decode at 512x512, bounded sample."""
-    from centerpose_amd import synth
-    from oracle import nets_torch
-    ncores = max(1, (os.cpu_count() or 2) // 2)          # physical cores (2 threads per core here)
-    ncores = min(ncores, 64)                              # one socket: oneDNN scales poorly across sockets
-    torch.set_num_threads(ncores)
-    sd = synth.make_state_dict(arch)
-    bs = 4
-    x = synth.make_images(bs)
-    nets_torch.process(arch, sd, x[:1])                   # warm-up (thread pool, oneDNN primitives)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        nets_torch.process(arch, sd, x)
-        n += bs
-        dt = time.perf_counter() - t0
-        if dt >= seconds or n >= 64:
-            break
-    return {"value": round(n / dt, 3), "unit": "images/sec", "cores": ncores, "kind": "port",
-            "sample": "%d images of 512x512 (%s forward + sigmoid + decode, torch %s CPU fp32) in %.1f s"
-                      % (n, arch, torch.__version__, dt)}
-
-
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--arch", default="dla_34")
     ap.add_argument("--batch", type=int, default=16, help="images per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel roofline pass (for rocprofv3 runs)")
     ap.add_argument("--no-graph", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` with no launcher around it: one process per GPU via torch.distributed.run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), CP_BENCH_CHILD="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(arch):
+    """Oracle ("port") on the host cores, 512x512, bounded sample: the metric's workload (forward + sigmoid + decode of
+    `arch`), and BASELINE.json configs[0] (res_50, single image; plus batch 8) split into forward and decode."""
+    import numpy as np
+    import torch
+    from centerpose_amd import synth
+    from oracle import decode_np, nets_torch
+    ncores = max(1, (os.cpu_count() or 2) // 2)          # physical cores (2 threads per core here)
+    ncores = min(ncores, 64)                              # one socket: oneDNN scales poorly across sockets
+    torch.set_num_threads(ncores)
+
+    def timed(a, x, min_s, max_imgs):
+        sd = synth.make_state_dict(a)
+        nets_torch.process(a, sd, x[:1])                  # warm-up (thread pool, oneDNN primitives)
+        n = fwd = dec = 0
+        t0 = time.perf_counter()
+        while True:
+            ta = time.perf_counter()
+            heads = [h.numpy() for h in nets_torch.forward(a, sd, x)]
+            sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+            tb = time.perf_counter()
+            decode_np.multi_pose_decode(sig(heads[0]), heads[1], heads[2], heads[3], sig(heads[4]), heads[5], K=100)
+            tc = time.perf_counter()
+            fwd, dec, n = fwd + tb - ta, dec + tc - tb, n + x.shape[0]
+            if tc - t0 >= min_s or n >= max_imgs:
+                return {"images": n, "seconds": round(tc - t0, 2), "images_per_sec": round(n / (tc - t0), 3),
+                        "forward_ms_per_image": round(fwd / n * 1e3, 2), "decode_ms_per_image": round(dec / n * 1e3, 2)}
+    main = timed(arch, synth.make_images(2), 8.0, 16)
+    r1 = timed("res_50", synth.make_images(1), 4.0, 32)
+    r8 = timed("res_50", synth.make_images(8), 3.0, 32)
+    return {"value": main["images_per_sec"], "unit": "images/sec", "cores": ncores, "kind": "port",
+            "sample": "%d images of 512x512 (%s forward + sigmoid + decode, batch 2, torch %s CPU fp32 oracle) in %.1f s"
+                      % (main["images"], arch, torch.__version__, main["seconds"]),
+            "cpu_model": cpu_model_name(), arch: main, "res_50_b1": r1, "res_50_b8": r8}
+
+
+def roofline(eng, arch, B):
+    """Per-family accounting of one step from in-sequence HIP-event timings (Engine.profile_in_sequence)."""
+    recs = eng.profile_in_sequence(iters=10)
+    fam = {}
+    for r in recs:
+        f = fam.setdefault(r["fn"], {"ms": 0.0, "flops": 0.0, "exe_flops": 0.0, "bytes": 0, "launches": 0})
+        f["ms"] += r["ms"]
+        f["flops"] += r["flops"]
+        f["exe_flops"] += r["flops"] * (16.0 / 36.0 if r["kind"] == "wino" else 1.0)    # F(2x2,3x3): 16 of 36 multiplies
+        f["bytes"] += r["bytes"]
+        f["launches"] += 1
+    all_ms = sum(f["ms"] for f in fam.values())
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    d = fam[dom]
+    mm = [fam[k] for k in fam if k in MFMA_FNS]
+    mm_ms = sum(f["ms"] for f in mm)
+    tf = lambda flops, ms: flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    exe = tf(d["exe_flops"], d["ms"])
+    roof = {"bound": "mfma", "kernel": KERNEL_OF.get(dom, dom), "achieved": round(exe, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+            "unit": "TFLOP/s", "frac": round(exe / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "definition": "achieved = MFMA FLOPs executed by the dominant kernel (largest share of the step's GPU time) / its "
+                          "time, HIP events between consecutive launches of the step; Winograd launches count 16/36 of their "
+                          "algorithmic FLOPs",
+            "algorithmic_tflops": round(tf(d["flops"], d["ms"]), 2),
+            "time_share": round(d["ms"] / all_ms, 4), "launches": d["launches"],
+            "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 1),
+            "families": {KERNEL_OF.get(k, k): {"ms_per_step": round(f["ms"], 3), "share": round(f["ms"] / all_ms, 4),
+                                               "launches": f["launches"],
+                                               "algorithmic_tflops": round(tf(f["flops"], f["ms"]), 1),
+                                               "executed_tflops": round(tf(f["exe_flops"], f["ms"]), 1),
+                                               "compulsory_tbps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e12, 2)}
+                         for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+            "all_mfma_kernels": {"ms_per_step": round(mm_ms, 3),
+                                 "algorithmic_tflops": round(tf(sum(f["flops"] for f in mm), mm_ms), 2),
+                                 "executed_tflops": round(tf(sum(f["exe_flops"] for f in mm), mm_ms), 2),
+                                 "executed_frac": round(tf(sum(f["exe_flops"] for f in mm), mm_ms) / PEAK_F32_MFMA_TFLOPS, 4)},
+            "all_kernels_ms_per_step": round(all_ms, 3),
+            "algorithmic_gflop_per_image": round(eng.flops_per_image / 1e9, 2)}
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction +
+    # WRITE_SIZE; separate --pmc runs of this same command, see profiles/README.md) -- NOT collected in this run
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+        if arch == "dla_34" and B == 16:
+            k = pmc["families"].get(dom)
+            if k:
+                roof["traffic"] = k["traffic_bytes_per_launch_avg"]
+                roof["traffic_unit"] = "bytes per launch (avg)"
+                roof["traffic_source"] = "profiles/r2_pmc_traffic.json (rocprofv3 --pmc, collected offline with this command)"
+    except (OSError, KeyError, ValueError):
+        pass
+    return roof
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args.gpus))
+
+    import torch
+    import torch.distributed as dist
     from centerpose_amd import dist as cpd
     from centerpose_amd import engine, synth
     from centerpose_amd.decode import multi_pose_decode
-    import torch.distributed as dist
 
     rank, world, local = cpd.init_from_env()
-    assert world == args.gpus, "launch with torchrun --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world)
+    assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     local = local % torch.cuda.device_count()     # (lets a 1-GPU box smoke-test the N>1 control flow over gloo)
     torch.cuda.set_device(local)
@@ -78,30 +189,38 @@ def main():
     lo, _ = cpd.shard_range(B * world, rank, world)
     images = synth.make_images(B, seed=317 + lo).to(dev)      # this rank's shard, resident in HBM
     eng.input.copy_(images)
+    gat = cpd.DetsGatherer(global_batch=B * world)
 
     def step():
+        """one batch through backbone + heads + decode; the all-gather of its detections is left running on the side
+        stream and collected one step later (the first call returns None)."""
         hm, wh, hps, reg, hm_hp, hp_offset = eng(eng.input)
         dets = multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset, K=100)
-        return cpd.gather_dets(dets) if world > 1 else dets
+        prev = gat.collect() if gat.pending else None
+        gat.submit(dets)
+        return prev
 
     for _ in range(args.warmup):
-        out = step()
+        step()
+    if gat.pending:
+        gat.collect()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ev0.record()
-    for _ in range(args.steps):
-        out = step()
-    ev1.record()
+    marks[0].record()
+    for i in range(args.steps):
+        step()
+        marks[i + 1].record()
+    out = gat.collect()                              # the last step's gather is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert out.shape == (B * world, 100, 56)
@@ -109,61 +228,38 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        # ---- roofline of the dominant kernel family, live HIP-event timing per launch ---------------
-        recs = eng.profile(iters=5)
-        mm = [r for r in recs if r["kind"] in ("conv", "wino", "dcn")]
-        mm_ms = sum(r["ms"] for r in mm)
-        mm_flops = sum(r["flops"] for r in mm)
-        all_ms = sum(r["ms"] for r in recs)
-        achieved = mm_flops / (mm_ms * 1e-3) / 1e12
-        # Winograd F(2x2,3x3) launches execute 16/36 of their algorithmic (direct-convolution) multiply-adds
-        exe_flops = sum(r["flops"] * (16.0 / 36.0 if r["kind"] == "wino" else 1.0) for r in mm)
-        # per-launch min-bound: a launch cannot finish before max(flop / MFMA peak, compulsory bytes / HBM bandwidth)
-        bound_ms = sum(max(r["flops"] / (PEAK_F32_MFMA_TFLOPS * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9)) for r in mm) * 1e3
-        roof = {"bound": "mfma", "kernel": "conv3x3_wino_kernel / igemm_conv_kernel / dcn_igemm_kernel (fp32 MFMA)",
-                "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                "executed_mfma_tflops": round(exe_flops / (mm_ms * 1e-3) / 1e12, 2),
-                "executed_frac": round(exe_flops / (mm_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                "winograd_launches": sum(1 for r in mm if r["kind"] == "wino"),
-                "min_bound_frac": round(bound_ms / mm_ms, 4),
-                "algorithmic_mb_per_step": round(sum(r["bytes"] for r in mm) / 1e6, 1),
-                "launches_per_step": len(mm), "gemm_ms_per_step": round(mm_ms, 3),
-                "all_kernels_ms_per_step": round(all_ms, 3),
-                "algorithmic_gflop_per_image": round(eng.flops_per_image / 1e9, 2),
-                "end_to_end_tflops": round(eng.flops_per_image * value / world / 1e12, 2)}
-        # HBM traffic per launch of the same kernel family from the committed rocprofv3 PMC passes
-        # (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE; collected offline, see profiles/README.md)
-        try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))
-            if args.arch == "dla_34" and B == 16:
-                roof["traffic"] = pmc["traffic_bytes_per_launch_avg"]
-                roof["traffic_unit"] = "bytes per launch (avg over the %d GEMM launches of a step)" % pmc["gemm_launches_per_step"]
-        except (OSError, KeyError, ValueError):
-            pass
+        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        pct = lambda q: per[min(len(per) - 1, int(q * len(per)))]
         line = {"metric": "images/sec end-to-end (backbone+decode), DLA-34 512x512", "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
                 "config": {"workload": "%s 512x512 batch=%d per GPU: HIP conv/DCNv2 backbone + heads + HIP heatmap "
-                                       "decode%s" % (args.arch, B, ", RCCL all-gather of decoded poses" if world > 1 else ""),
+                                       "decode%s" % (args.arch, B, ", RCCL all-gather of decoded poses (side stream)" if world > 1 else ""),
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
                            "weights": "seeded synthetic checkpoint (reference key layout)"},
-                "roofline": roof}
-        # ---- decode alone (latency-bound; reported as us/batch next to its HBM GB/s) ------------------
-        hm, wh, hps, reg, hm_hp, hp_offset = eng.outputs
-        for _ in range(3):
-            multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset, K=100)
-        d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        d0.record()
-        for _ in range(20):
-            multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset, K=100)
-        d1.record()
-        d1.synchronize()
-        dec_us = d0.elapsed_time(d1) / 20 * 1e3
-        dec_bytes = B * (18 * hm.shape[2] * hm.shape[3] * 4 + 28800 + 22400)     # hm + hm_hp maps, gathers, dets
-        line["decode"] = {"us_per_batch": round(dec_us, 1), "algorithmic_bytes": dec_bytes,
-                          "gbps": round(dec_bytes / dec_us / 1e3, 1), "kernels": "nms_topk_kernel + pose_assign_kernel"}
+                "ranks": dist.get_world_size() if world > 1 else 1,
+                "backend": dist.get_backend() if world > 1 else None,
+                "step_ms": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3),
+                            "min": round(per[0], 3), "max": round(per[-1], 3), "source": "HIP events per step on the launch stream"},
+                "end_to_end_tflops": round(eng.flops_per_image * value / world / 1e12, 2),
+                "activation_mb": round(eng.activation_bytes / 1e6, 1)}
+        if not args.no_profile:
+            line["roofline"] = roofline(eng, args.arch, B)
+            # ---- decode alone (latency-bound; reported as us/batch next to its HBM GB/s) ------------------
+            hm, wh, hps, reg, hm_hp, hp_offset = eng.outputs
+            for _ in range(3):
+                multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset, K=100)
+            d0, d1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            d0.record()
+            for _ in range(20):
+                multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset, K=100)
+            d1.record()
+            d1.synchronize()
+            dec_us = d0.elapsed_time(d1) / 20 * 1e3
+            dec_bytes = B * (18 * hm.shape[2] * hm.shape[3] * 4 + 28800 + 22400)     # hm + hm_hp maps, gathers, dets
+            line["decode"] = {"us_per_batch": round(dec_us, 1), "algorithmic_bytes": dec_bytes,
+                              "gbps": round(dec_bytes / dec_us / 1e3, 1), "kernels": "nms_topk_kernel + pose_assign_kernel"}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch)
         print(json.dumps(line), flush=True)

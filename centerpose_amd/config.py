@@ -43,13 +43,13 @@ _DEFAULTS = {
              "NMS": False, "NMS_THRE": 0.5, "FIX_RES": True, "VIS_THRESH": 0.3},                   # :143-159
 }
 
-ARCH_PRESETS = {  # the per-architecture values of experiments/{dla_34,res_50}_512x512.yaml, hrnet_w32_512.yaml
+ARCH_PRESETS = {  # the MODEL / TEST values of experiments/dla_34_512x512.yaml, res_50_512x512.yaml, hrnet_w32_512.yaml
     "dla_34": {"MODEL": {"NAME": "dla_34", "HEAD_CONV": 256, "INTERMEDIATE_CHANNEL": 64},
-               "TEST": {"FLIP_TEST": True, "NMS": True, "FIX_RES": False}},
+               "TEST": {"FLIP_TEST": True, "NMS": True, "FIX_RES": False, "TEST_SCALES": [1]}},           # :119-131
     "res_50": {"MODEL": {"NAME": "res_50", "HEAD_CONV": 64, "INTERMEDIATE_CHANNEL": 256},
-               "TEST": {"NMS": False, "FIX_RES": True}},
+               "TEST": {"FLIP_TEST": True, "NMS": False, "FIX_RES": True, "TEST_SCALES": [1]}},           # :119-131
     "hrnet": {"MODEL": {"NAME": "hrnet", "HEAD_CONV": 64, "INTERMEDIATE_CHANNEL": 32},
-              "TEST": {"TEST_SCALES": [1, 2]}},
+              "TEST": {"FLIP_TEST": True, "NMS": False, "FIX_RES": False, "TEST_SCALES": [1, 2]}},        # :131-143
 }
 
 

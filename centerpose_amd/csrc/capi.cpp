@@ -14,5 +14,5 @@ void cp_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* cp_last_error(void) { return g_err; }
-extern "C" int cp_abi_version(void) { return 1; }
+extern "C" int cp_abi_version(void) { return 2; }      // 2: plan handle (cp_plan_*), decode of any map size
 extern "C" const char* cp_target_arch(void) { return "gfx950"; }

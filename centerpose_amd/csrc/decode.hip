@@ -10,6 +10,11 @@
 //                          become order-preserving uint32 keys in LDS; a 4-pass 8-bit radix
 //                          select finds the K-th largest key; survivors are compacted and
 //                          bitonic-sorted.  Order = (value desc, flat index asc).
+//                          Planes above 32768 keys (FIX_RES = false inputs, TEST_SCALES > 1: the reference's
+//                          torch.topk has no size limit, decode.py:87-115) are streamed through LDS in equal
+//                          chunks: each chunk's top-K (same order rule, global flat indices) is merged into the
+//                          running top-K by a 2P-wide bitonic sort -- the union of per-chunk top-Ks contains the
+//                          plane's top-K, so the result is the same (value desc, index asc) list.
 //   K7 pose_assign_kernel: one workgroup per (image, joint): gathers hps/reg/wh/hp_offset
 //                          straight from the NCHW maps at the K peaks (no whole-map transpose),
 //                          does the K x K nearest-candidate search from LDS, applies the
@@ -41,7 +46,8 @@ __device__ __forceinline__ float key2f(uint32_t k)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TK_THREADS) void nms_topk_kernel(
     const float* __restrict__ heat, const float* __restrict__ hm_hp, int cat, int J, int H, int W,
-    int K, int P /* pow2 >= K */, int nmax /* LDS key slots, multiple of 4 */, float* __restrict__ out_scores, int* __restrict__ out_inds)
+    int K, int P /* pow2 >= K */, int nmax /* LDS key slots, multiple of 4 */, int chunk /* keys per pass through LDS, <= nmax */,
+    float* __restrict__ out_scores, int* __restrict__ out_inds)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -54,14 +60,20 @@ __global__ __launch_bounds__(TK_THREADS) void nms_topk_kernel(
     else { src = hm_hp + ((size_t)b * J + (pl - 1)) * HW; n = HW; }
 
     uint32_t* keys = reinterpret_cast<uint32_t*>(smem);                    // [nmax]
-    unsigned long long* cand = reinterpret_cast<unsigned long long*>(smem + (size_t)nmax * 4);  // [TK_MAX_K]
-    uint32_t* hist = reinterpret_cast<uint32_t*>(cand + TK_MAX_K);         // [256]
+    unsigned long long* cand0 = reinterpret_cast<unsigned long long*>(smem + (size_t)nmax * 4);  // [2 * TK_MAX_K]: running top-P | this chunk's
+    uint32_t* hist = reinterpret_cast<uint32_t*>(cand0 + 2 * TK_MAX_K);    // [256]
     uint32_t* wsum = hist + 256;                                           // [TK_WAVES]
     uint32_t* sctl = wsum + TK_WAVES;                                      // [4] digit, remaining, cnt_gt
 
+    const int ntot = n;
+    for (int c0 = 0; c0 < ntot; c0 += chunk) {
+    // keys of flat indices [c0, c0 + n) live in LDS; candidates carry the global index c0 + e
+    n = min(chunk, ntot - c0);
+    unsigned long long* cand = c0 == 0 ? cand0 : cand0 + P;
+    __syncthreads();      // previous chunk's merge has finished with keys / cand
     // ---- phase 1: 3x3 NMS (decode.py:10-16; -inf padding == skip out-of-range) -> keys
     for (int e = tid; e < n; e += TK_THREADS) {
-        const int c = e / HW, p = e - c * HW;
+        const int c = (c0 + e) / HW, p = (c0 + e) - c * HW;
         const int y = p / W, x = p - y * W;
         const float* pp = src + (size_t)c * HW;
         const float v = pp[p];
@@ -78,7 +90,8 @@ __global__ __launch_bounds__(TK_THREADS) void nms_topk_kernel(
 
     // ---- phase 2: radix select of the K-th largest key (MSB first, 8 bits per pass)
     uint32_t prefix = 0, pmask = 0;
-    int remaining = K;
+    int remaining = min(K, n);
+    const int Kc = remaining;
     for (int pass = 0; pass < 4; ++pass) {
         const int shift = 24 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
@@ -131,7 +144,7 @@ __global__ __launch_bounds__(TK_THREADS) void nms_topk_kernel(
     }
     const uint32_t T = prefix;          // K-th largest key
     const int need_eq = remaining;      // how many keys == T to take (lowest indices first)
-    const int cnt_gt = K - need_eq;
+    const int cnt_gt = Kc - need_eq;
 
     // ---- phase 3: compaction.  key > T: any slot in [0,cnt_gt).  key == T: index-ordered rank.
     if (tid == 0) sctl[2] = 0;
@@ -157,32 +170,35 @@ __global__ __launch_bounds__(TK_THREADS) void nms_topk_kernel(
         if (eq) {
             const uint32_t rank = eq_base + (uint32_t)__popcll(em & ((1ull << lane) - 1ull));
             if (rank < (uint32_t)need_eq)
-                cand[cnt_gt + rank] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)e);
+                cand[cnt_gt + rank] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(c0 + e));
         }
         eq_base += (uint32_t)__popcll(em);
         if (gt) {
             const uint32_t slot = atomicAdd(&sctl[2], 1u);
-            cand[slot] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)e);
+            cand[slot] = ((unsigned long long)k << 32) | (uint32_t)(0xFFFFFFFFu - (uint32_t)(c0 + e));
         }
     }
     __syncthreads();
 
-    // ---- phase 4: bitonic sort of P candidates, descending (value desc, index asc)
-    for (int k2 = 2; k2 <= P; k2 <<= 1) {
+    // ---- phase 4: bitonic sort, descending (value desc, index asc): the first chunk's P candidates, afterwards the
+    // running top-P together with this chunk's P candidates (the better half stays in cand0[0, P))
+    const int S = c0 == 0 ? P : 2 * P;
+    for (int k2 = 2; k2 <= S; k2 <<= 1) {
         for (int j = k2 >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += TK_THREADS) {
+            for (int i = tid; i < S; i += TK_THREADS) {
                 const int ixj = i ^ j;
                 if (ixj > i) {
-                    const unsigned long long a = cand[i], c = cand[ixj];
+                    const unsigned long long a = cand0[i], c = cand0[ixj];
                     const bool desc = ((i & k2) == 0);
-                    if (desc ? (a < c) : (a > c)) { cand[i] = c; cand[ixj] = a; }
+                    if (desc ? (a < c) : (a > c)) { cand0[i] = c; cand0[ixj] = a; }
                 }
             }
             __syncthreads();
         }
     }
+    }   // chunk loop
     for (int i = tid; i < K; i += TK_THREADS) {
-        const unsigned long long c = cand[i];
+        const unsigned long long c = cand0[i];
         out_scores[(size_t)blockIdx.x * K + i] = key2f((uint32_t)(c >> 32));
         out_inds[(size_t)blockIdx.x * K + i] = (int)(0xFFFFFFFFu - (uint32_t)(c & 0xFFFFFFFFull));
     }
@@ -266,13 +282,17 @@ extern "C" int cp_multi_pose_decode_f32(const float* heat, const float* wh, cons
                  "multi_pose_decode: hm_hp is required (the reference raises NameError without it, decode.py:307)");
     CP_CHECK_ARG(B > 0 && cat > 0 && J > 0 && H > 0 && W > 0, "multi_pose_decode: bad shape");
     CP_CHECK_ARG(K > 0 && K <= TK_MAX_K, "multi_pose_decode: K=%d out of range (1..%d)", K, TK_MAX_K);
-    CP_CHECK_ARG((long long)cat * H * W <= TK_MAX_ELEMS, "multi_pose_decode: cat*H*W=%lld exceeds the LDS-resident limit %d",
-                 (long long)cat * H * W, TK_MAX_ELEMS);
+    CP_CHECK_ARG((long long)cat * H * W < (1ll << 31), "multi_pose_decode: cat*H*W=%lld does not fit a 32-bit flat index",
+                 (long long)cat * H * W);
     CP_CHECK_ARG(H * W >= K, "multi_pose_decode: K=%d larger than the map (%d)", K, H * W);
     int P = 1;
     while (P < K) P <<= 1;
-    const int nmax = ((cat * H * W > H * W ? cat * H * W : H * W) + 3) & ~3;
-    const size_t lds = (size_t)nmax * 4 + TK_MAX_K * 8 + 256 * 4 + TK_WAVES * 4 + 16;
+    // planes up to TK_MAX_ELEMS keys are LDS-resident in one piece; larger ones stream through LDS in equal chunks
+    const int nbig = cat * H * W;
+    const int nchunks = cp_cdiv(nbig, TK_MAX_ELEMS);
+    const int chunk = (cp_cdiv(nbig, nchunks) + 3) & ~3;
+    const int nmax = chunk;
+    const size_t lds = (size_t)nmax * 4 + 2 * TK_MAX_K * 8 + 256 * 4 + TK_WAVES * 4 + 16;
     static size_t lds_reserved = 0;   // one device per process (one rank per GPU)
     if (lds > lds_reserved) {
         hipError_t e = hipFuncSetAttribute((const void*)nms_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -281,7 +301,7 @@ extern "C" int cp_multi_pose_decode_f32(const float* heat, const float* wh, cons
     }
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(nms_topk_kernel, dim3(B * (1 + J)), dim3(TK_THREADS), lds, s, heat, hm_hp, cat, J, H, W, K, P,
-                       nmax, ws_scores, ws_inds);
+                       nmax, chunk, ws_scores, ws_inds);
     CP_CHECK_LAUNCH("nms_topk_kernel");
     hipLaunchKernelGGL(pose_assign_kernel, dim3(B * J), dim3(128), 0, s, wh, kps, reg, hp_offset, ws_scores, ws_inds, J,
                        H, W, K, dets);

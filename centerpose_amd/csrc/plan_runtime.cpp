@@ -1,0 +1,330 @@
+// Plan handle of the C ABI: cp_plan_load / cp_plan_create / cp_plan_forward / cp_plan_process /
+// cp_plan_destroy.  A plan file (layout: centerpose_amd/plan.py) is the compiled form of
+// BackBoneWithHead.forward (lib/models/model.py:57-59) for one (arch, B, H, W): the packed constants and the schedule of
+// C-ABI kernel launches.  This file only replays that schedule -- the same records `ops.Launch.run` executes from Python --
+// so a C/C++ caller runs the network, and the whole of MultiPoseDetector.process (lib/detectors/multi_pose.py:29-60:
+// forward, sigmoid (fused), decode), without any Python.  The handle owns all device memory it allocates.
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "common.h"
+
+extern "C" {
+struct cp_conv_desc;
+struct cp_dcn_desc;
+int cp_abi_version(void);
+int cp_conv2d_f32(const cp_conv_desc*, const float* const*, const float*, const float*, const float*, const float*, float*, void*);
+int cp_conv3x3_winograd_f32(const cp_conv_desc*, const float*, const float*, const float*, const float*, const float*, float*, void*);
+int cp_dcn_v2_f32(const cp_dcn_desc*, const float*, const float*, const float*, const float*, const float*, float*, void*);
+int cp_stem7x7_f32(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, void*);
+int cp_maxpool2d_nhwc_f32(const float*, int, float*, int, int, int, int, int, int, int, int, void*);
+int cp_dw_deconv_add_nhwc_f32(const float*, int, const float*, const float*, int, float*, int, int, int, int, int, int, void*);
+int cp_sum_up_nhwc_f32(int, const float* const*, const int*, const int*, float*, int, int, int, int, int, int, void*);
+int cp_multi_pose_decode_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int,
+                             int, int, float*, float*, int*, void*);
+}
+
+namespace {
+
+enum { FN_CONV = 1, FN_WINO = 2, FN_DCN = 3, FN_STEM7 = 4, FN_POOL = 5, FN_UPADD = 6, FN_SUMUP = 7 };   // ops.FN_IDS
+enum { REF_NULL = 0, REF_BUF = 1, REF_CONST = 2 };
+
+struct Op {
+    uint32_t fn = 0, out_index = 0;
+    std::vector<unsigned char> desc;
+    std::vector<float*> ptrs;
+    std::vector<int> ints;
+};
+
+struct Out { float* p; int shape[4]; };
+
+}  // namespace
+
+struct cp_plan {
+    int B = 0, H = 0, W = 0;
+    std::vector<float*> bufs, consts;
+    float* input = nullptr;
+    std::vector<Out> outs;
+    std::vector<Op> ops;
+    bool use_graph = false, warmed = false;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    // decode workspace of cp_plan_process (allocated on first use)
+    float* ws_scores = nullptr;
+    int* ws_inds = nullptr;
+    int ws_K = 0;
+};
+
+namespace {
+
+struct Reader {
+    const unsigned char* b;
+    size_t n, p = 0;
+    bool ok = true;
+    bool take(void* dst, size_t k) {
+        if (p + k > n) { ok = false; return false; }
+        memcpy(dst, b + p, k);
+        p += k;
+        return true;
+    }
+    uint32_t u32() { uint32_t v = 0; take(&v, 4); return v; }
+    uint64_t u64() { uint64_t v = 0; take(&v, 8); return v; }
+    void skip_pad8() { p += (8 - (p & 7)) & 7; }
+};
+
+struct Ref { uint32_t kind, id; uint64_t off, numel; };
+
+int run_op(const Op& o, hipStream_t s)
+{
+    const std::vector<float*>& P = o.ptrs;
+    const int* I = o.ints.data();
+    switch (o.fn) {
+        case FN_CONV:
+            return cp_conv2d_f32(reinterpret_cast<const cp_conv_desc*>(o.desc.data()), reinterpret_cast<const float* const*>(P.data()), P[4],
+                                 P[5], P[6], P[7], P[8], s);
+        case FN_WINO:
+            return cp_conv3x3_winograd_f32(reinterpret_cast<const cp_conv_desc*>(o.desc.data()), P[0], P[1], P[2], P[3], P[4], P[5], s);
+        case FN_DCN:
+            return cp_dcn_v2_f32(reinterpret_cast<const cp_dcn_desc*>(o.desc.data()), P[0], P[1], P[2], P[3], P[4], P[5], s);
+        case FN_STEM7:
+            return cp_stem7x7_f32(P[0], P[1], P[2], P[3], P[4], I[0], I[1], I[2], I[3], I[4], I[5], I[6], s);
+        case FN_POOL:
+            return cp_maxpool2d_nhwc_f32(P[0], I[0], P[1], I[1], I[2], I[3], I[4], I[5], I[6], I[7], I[8], s);
+        case FN_UPADD:
+            return cp_dw_deconv_add_nhwc_f32(P[0], I[0], P[1], P[2], I[1], P[3], I[2], I[3], I[4], I[5], I[6], I[7], s);
+        case FN_SUMUP:
+            return cp_sum_up_nhwc_f32(I[0], reinterpret_cast<const float* const*>(P.data()), I + 1, I + 5, P[4], I[9], I[10], I[11], I[12],
+                                      I[13], I[14], s);
+    }
+    cp_set_error("plan: unknown launch function %u", o.fn);
+    return 1;
+}
+
+// (pointer count, integer count) every entry point expects -- a malformed file must not index out of range
+bool arity_ok(const Op& o)
+{
+    switch (o.fn) {
+        case FN_CONV: return o.ptrs.size() == 9 && o.desc.size() >= 4;
+        case FN_WINO: case FN_DCN: return o.ptrs.size() == 6 && o.desc.size() >= 4;
+        case FN_STEM7: return o.ptrs.size() == 5 && o.ints.size() == 7;
+        case FN_POOL: return o.ptrs.size() == 2 && o.ints.size() == 9;
+        case FN_UPADD: return o.ptrs.size() == 4 && o.ints.size() == 8;
+        case FN_SUMUP: return o.ptrs.size() == 5 && o.ints.size() == 15;
+    }
+    return false;
+}
+
+int run_all(cp_plan* pl, hipStream_t s)
+{
+    for (const Op& o : pl->ops)
+        if (int rc = run_op(o, s)) return rc;
+    return 0;
+}
+
+void free_plan(cp_plan* pl)
+{
+    if (!pl) return;
+    if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
+    if (pl->graph) (void)hipGraphDestroy(pl->graph);
+    if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
+    for (float* p : pl->bufs) if (p) (void)hipFree(p);
+    for (float* p : pl->consts) if (p) (void)hipFree(p);
+    if (pl->ws_scores) (void)hipFree(pl->ws_scores);
+    if (pl->ws_inds) (void)hipFree(pl->ws_inds);
+    delete pl;
+}
+
+#define PLAN_FAIL(...)            \
+    do {                          \
+        cp_set_error(__VA_ARGS__); \
+        free_plan(pl);            \
+        return 1;                 \
+    } while (0)
+
+}  // namespace
+
+extern "C" int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_plan** out)
+{
+    CP_CHECK_ARG(blob && out, "plan_create: null pointer");
+    *out = nullptr;
+    Reader r{static_cast<const unsigned char*>(blob), bytes};
+    CP_CHECK_ARG(bytes >= 48 && memcmp(blob, "CPPLAN02", 8) == 0, "plan_create: not a centerpose_amd plan (bad magic)");
+    r.p = 8;
+    const uint32_t abi = r.u32(), B = r.u32(), H = r.u32(), W = r.u32(), nbuf = r.u32(), nconst = r.u32(), nops = r.u32(),
+                   nout = r.u32(), mlen = r.u32();
+    (void)r.u32();
+    CP_CHECK_ARG((int)abi == cp_abi_version(), "plan_create: plan was written for ABI %u, library has %d", abi, cp_abi_version());
+    CP_CHECK_ARG(nbuf < (1u << 20) && nconst < (1u << 20) && nops < (1u << 20) && nout <= 64 && mlen < bytes,
+                 "plan_create: corrupt header");
+    r.p += mlen;
+    r.skip_pad8();
+    cp_plan* pl = new cp_plan();
+    pl->B = (int)B; pl->H = (int)H; pl->W = (int)W;
+    pl->use_graph = use_graph != 0;
+    std::vector<uint64_t> buf_numel(nbuf);
+    for (uint32_t i = 0; i < nbuf; ++i) buf_numel[i] = r.u64();
+    struct CI { uint64_t numel, off; };
+    std::vector<CI> ci(nconst);
+    for (uint32_t i = 0; i < nconst; ++i) { ci[i].numel = r.u64(); ci[i].off = r.u64(); }
+    if (!r.ok) PLAN_FAIL("plan_create: truncated file (tables)");
+    for (uint32_t i = 0; i < nconst; ++i)
+        if (ci[i].off > bytes || ci[i].numel * 4 > bytes - ci[i].off) PLAN_FAIL("plan_create: constant %u lies outside the file", i);
+    // ---- device memory: activations (zero-filled once) and constants
+    pl->bufs.assign(nbuf, nullptr);
+    pl->consts.assign(nconst, nullptr);
+    for (uint32_t i = 0; i < nbuf; ++i) {
+        if (hipMalloc((void**)&pl->bufs[i], buf_numel[i] * 4 + 16) != hipSuccess) PLAN_FAIL("plan_create: hipMalloc of %llu floats failed", (unsigned long long)buf_numel[i]);
+        (void)hipMemset(pl->bufs[i], 0, buf_numel[i] * 4);
+    }
+    for (uint32_t i = 0; i < nconst; ++i) {
+        if (hipMalloc((void**)&pl->consts[i], ci[i].numel * 4 + 16) != hipSuccess) PLAN_FAIL("plan_create: hipMalloc (constant) failed");
+        if (hipMemcpy(pl->consts[i], r.b + ci[i].off, ci[i].numel * 4, hipMemcpyHostToDevice) != hipSuccess)
+            PLAN_FAIL("plan_create: upload of constant %u failed", i);
+    }
+    bool bad_ref = false;
+    auto resolve = [&](Reader& rd) -> float* {
+        Ref f;
+        f.kind = rd.u32(); f.id = rd.u32(); f.off = rd.u64(); f.numel = rd.u64();
+        if (f.kind == REF_NULL) return nullptr;
+        if (f.kind == REF_BUF && f.id < nbuf && f.off < buf_numel[f.id]) return pl->bufs[f.id] + f.off;
+        if (f.kind == REF_CONST && f.id < nconst) return pl->consts[f.id];
+        bad_ref = true;
+        return nullptr;
+    };
+    pl->input = resolve(r);
+    if (!pl->input) PLAN_FAIL("plan_create: plan has no input buffer");
+    for (uint32_t i = 0; i < nout; ++i) {
+        Out o;
+        o.p = resolve(r);
+        for (int k = 0; k < 4; ++k) o.shape[k] = (int)r.u32();
+        pl->outs.push_back(o);
+    }
+    pl->ops.resize(nops);
+    for (uint32_t i = 0; i < nops && r.ok; ++i) {
+        Op& o = pl->ops[i];
+        o.fn = r.u32();
+        const uint32_t dlen = r.u32(), nptr = r.u32(), nint = r.u32();
+        o.out_index = r.u32();
+        (void)r.u32();
+        if (dlen > 4096 || nptr > 64 || nint > 64) { r.ok = false; break; }
+        o.desc.resize(dlen);
+        if (dlen) r.take(o.desc.data(), dlen);
+        r.skip_pad8();
+        for (uint32_t k = 0; k < nptr; ++k) o.ptrs.push_back(resolve(r));
+        o.ints.resize(nint);
+        if (nint) r.take(o.ints.data(), 4 * (size_t)nint);
+        r.skip_pad8();
+        if (!arity_ok(o)) PLAN_FAIL("plan_create: op %u (function %u) has the wrong number of arguments", i, o.fn);
+    }
+    if (!r.ok || bad_ref) PLAN_FAIL("plan_create: truncated or inconsistent file (schedule)");
+    if (hipDeviceSynchronize() != hipSuccess) PLAN_FAIL("plan_create: device error after upload");
+    *out = pl;
+    return 0;
+}
+
+extern "C" int cp_plan_load(const char* path, int use_graph, cp_plan** out)
+{
+    CP_CHECK_ARG(path && out, "plan_load: null pointer");
+    FILE* f = fopen(path, "rb");
+    CP_CHECK_ARG(f != nullptr, "plan_load: cannot open %s", path);
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<unsigned char> blob(n > 0 ? (size_t)n : 0);
+    const size_t got = n > 0 ? fread(blob.data(), 1, (size_t)n, f) : 0;
+    fclose(f);
+    CP_CHECK_ARG(n > 0 && got == (size_t)n, "plan_load: short read of %s", path);
+    return cp_plan_create(blob.data(), blob.size(), use_graph, out);
+}
+
+extern "C" int cp_plan_info(const cp_plan* pl, int* B, int* H, int* W, int* n_outputs, int* n_launches)
+{
+    CP_CHECK_ARG(pl, "plan_info: null plan");
+    if (B) *B = pl->B;
+    if (H) *H = pl->H;
+    if (W) *W = pl->W;
+    if (n_outputs) *n_outputs = (int)pl->outs.size();
+    if (n_launches) *n_launches = (int)pl->ops.size();
+    return 0;
+}
+
+extern "C" float* cp_plan_input(const cp_plan* pl) { return pl ? pl->input : nullptr; }
+
+extern "C" int cp_plan_output(const cp_plan* pl, int i, float** dev_ptr, int shape[4])
+{
+    CP_CHECK_ARG(pl && i >= 0 && i < (int)pl->outs.size(), "plan_output: index %d out of range", i);
+    if (dev_ptr) *dev_ptr = pl->outs[i].p;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = pl->outs[i].shape[k];
+    return 0;
+}
+
+extern "C" int cp_plan_forward(cp_plan* pl, const float* images, void* stream)
+{
+    CP_CHECK_ARG(pl, "plan_forward: null plan");
+    hipStream_t s = (hipStream_t)stream;
+    if (images && images != pl->input) {
+        hipError_t e = hipMemcpyAsync(pl->input, images, (size_t)pl->B * 3 * pl->H * pl->W * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { cp_set_error("plan_forward: input copy failed: %s", hipGetErrorString(e)); return 2; }
+    }
+    if (!pl->use_graph) return run_all(pl, s);
+    if (!pl->exec) {
+        // first call: one eager pass (sets kernel attributes, loads code objects), then capture the schedule once
+        if (int rc = run_all(pl, s)) return rc;
+        if (hipStreamSynchronize(s) != hipSuccess) { cp_set_error("plan_forward: warm-up pass failed"); return 2; }
+        if (hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) != hipSuccess) { cp_set_error("plan_forward: stream create"); return 2; }
+        if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { cp_set_error("plan_forward: begin capture"); return 2; }
+        const int rc = run_all(pl, pl->cap_stream);
+        hipError_t e = hipStreamEndCapture(pl->cap_stream, &pl->graph);
+        if (rc) return rc;
+        if (e != hipSuccess || !pl->graph) { cp_set_error("plan_forward: end capture: %s", hipGetErrorString(e)); return 2; }
+        e = hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { cp_set_error("plan_forward: graph instantiate: %s", hipGetErrorString(e)); pl->exec = nullptr; return 2; }
+        return 0;      // the warm-up pass already produced this call's outputs
+    }
+    hipError_t e = hipGraphLaunch(pl->exec, s);
+    if (e != hipSuccess) { cp_set_error("plan_forward: graph launch: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+// MultiPoseDetector.process (lib/detectors/multi_pose.py:29-60) without the flip test: forward (hm / hm_hp sigmoided in the
+// head epilogue) + multi_pose_decode.  The plan's outputs must be the reference's six heads in order
+// [hm, wh, hps, reg, hm_hp, hp_offset] (lib/models/heads/keypoint.py:40-42).
+extern "C" int cp_plan_process(cp_plan* pl, const float* images, int K, float* dets, void* stream)
+{
+    CP_CHECK_ARG(pl && dets, "plan_process: null pointer");
+    CP_CHECK_ARG(pl->outs.size() == 6, "plan_process: the plan has %zu outputs, expected the six heads", pl->outs.size());
+    const Out& hm = pl->outs[0];
+    const int B = hm.shape[0], cat = hm.shape[1], Hm = hm.shape[2], Wm = hm.shape[3];
+    const int J = pl->outs[4].shape[1];
+    CP_CHECK_ARG(pl->outs[2].shape[1] == 2 * J, "plan_process: hps has %d channels, hm_hp %d", pl->outs[2].shape[1], J);
+    if (int rc = cp_plan_forward(pl, images, stream)) return rc;
+    if (pl->ws_K < K) {
+        if (pl->ws_scores) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(pl->ws_scores); (void)hipFree(pl->ws_inds); }
+        pl->ws_scores = nullptr; pl->ws_inds = nullptr; pl->ws_K = 0;
+        const size_t n = (size_t)B * (1 + J) * K;
+        if (hipMalloc((void**)&pl->ws_scores, n * 4) != hipSuccess || hipMalloc((void**)&pl->ws_inds, n * 4) != hipSuccess) {
+            cp_set_error("plan_process: workspace allocation failed");
+            return 2;
+        }
+        pl->ws_K = K;
+    }
+    return cp_multi_pose_decode_f32(hm.p, pl->outs[1].p, pl->outs[2].p, pl->outs[3].p, pl->outs[4].p, pl->outs[5].p, B, cat, J, Hm, Wm, K,
+                                    dets, pl->ws_scores, pl->ws_inds, stream);
+}
+
+extern "C" int cp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)
+{
+    CP_CHECK_ARG(dst && src, "memcpy_d2d: null pointer");
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+    if (e != hipSuccess) { cp_set_error("memcpy_d2d: %s", hipGetErrorString(e)); return 2; }
+    return 0;
+}
+
+extern "C" int cp_plan_destroy(cp_plan* pl)
+{
+    if (pl) (void)hipDeviceSynchronize();
+    free_plan(pl);
+    return 0;
+}

@@ -3,44 +3,92 @@
 (lib/detectors/multi_pose.py:24-79), so the class drops in behind tools/demo.py:47-49,77 and
 tools/evaluate.py:48-67 (``detector_factory['multi_pose'](cfg).run(path)``).
 
-Differences, all documented in INTEGRATION.md:
-* the model is the fused HIP engine (model.BackBoneWithHead); hm / hm_hp come out of the head
-  kernel already sigmoided, so ``process`` has no separate sigmoid pass;
-* the flip-test merge runs on the device (the reference bounces through numpy, models/utils.py:30-47);
-* ``process`` accepts any batch size when FLIP_TEST is off (the reference is batch-1 by
-  construction, multi_pose.py:63) -- that is the batched throughput path of BASELINE.json;
-* image decoding / warpAffine need cv2 in the reference; here ``pre_process`` uses a small numpy
-  bilinear warp (cv2 is not a dependency).
+What is kept is the CONTRACT -- method names and signatures, the meta dict, the seven timing buckets and the result
+dict of ``run`` -- not the reference's statement order: the stages are organised around a small stage clock and an input
+source object, every pixel / tensor stage runs on the device:
+
+* ``pre_process``: upload of the uint8 image, then cv2.resize / cv2.warpAffine / normalise / HWC->CHW (+ mirrored twin) as
+  two HIP kernels that restate OpenCV's 8-bit fixed-point arithmetic (csrc/prepost.hip) -- cv2 is not a dependency;
+* ``process``: fused HIP engine (hm / hm_hp leave the head kernel already sigmoided), device flip-test merge (the reference
+  bounces through numpy, models/utils.py:30-47), HIP decode; any batch size when FLIP_TEST is off (the reference is batch-1
+  by construction, multi_pose.py:63) -- that is the batched throughput path of BASELINE.json;
+* ``post_process``: inverse affine of boxes / keypoints as one HIP kernel, one D2H copy;
+* ``merge_outputs``: soft-NMS on the host (C++, csrc/host_nms.cpp).
 """
+import ctypes
 import time
 
 import numpy as np
 import torch
 
-from . import _lib, ops
+from . import _lib
 from .decode import multi_pose_decode
 from .model import create_model, load_model
-from .post_process import get_affine_transform, multi_pose_post_process
+from .post_process import get_affine_transform
 
 FLIP_IDX = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]   # multi_pose.py:27
 
 
-def _warp_affine_bilinear(img, M, out_w, out_h):
-    """cv2.warpAffine(img, M, (out_w,out_h), flags=INTER_LINEAR) stand-in (border = 0), float math."""
-    Mi = np.linalg.inv(np.vstack([M, [0, 0, 1]]))[:2]
-    ys, xs = np.mgrid[0:out_h, 0:out_w].astype(np.float64)
-    sx = Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]
-    sy = Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]
-    x0, y0 = np.floor(sx).astype(np.int64), np.floor(sy).astype(np.int64)
-    fx, fy = sx - x0, sy - y0
-    H, W = img.shape[:2]
-    out = np.zeros((out_h, out_w, img.shape[2]), np.float64)
-    for dy, dx, wgt in ((0, 0, (1 - fy) * (1 - fx)), (0, 1, (1 - fy) * fx), (1, 0, fy * (1 - fx)), (1, 1, fy * fx)):
-        yy, xx = y0 + dy, x0 + dx
-        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
-        v = img[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)].astype(np.float64)
-        out += v * (wgt * ok)[..., None]
-    return out
+class StageClock:
+    """The seven wall-clock buckets of BaseDetector.run (base_detector.py:80-81,138-140).  `lap(key)` synchronises the
+    device and charges the time since the previous mark to `key`; `split(key, at)` charges up to an externally taken
+    time stamp (process() reports when the forward finished)."""
+    KEYS = ("tot", "load", "pre", "net", "dec", "post", "merge")
+
+    def __init__(self, sync):
+        self._sync = sync
+        self.t = dict.fromkeys(self.KEYS, 0)
+        self._start = self._mark = time.time()
+
+    def lap(self, key, sync=True):
+        if sync:
+            self._sync()
+        now = time.time()
+        self.t[key] += now - self._mark
+        self._mark = now
+
+    def split(self, key, at):
+        self.t[key] += at - self._mark
+        self._mark = at
+
+    def report(self, results):
+        self.t["tot"] += self._mark - self._start
+        out = {"results": {1: results}}
+        out.update(self.t)
+        return out
+
+
+class _ArraySource:
+    """run() input that still needs pre-processing: an HxWx3 uint8 BGR array (what cv2.imread returns)."""
+
+    def __init__(self, image):
+        self.image = image
+
+    def at_scale(self, det, scale, meta):
+        return det.pre_process(self.image, scale, meta)
+
+
+class _PreparedSource:
+    """run() input from the evaluation data loader: {'image', 'images': {scale: tensor}, 'meta': {scale: dict of tensors}}
+    (base_detector.py:91-93,103-106)."""
+
+    def __init__(self, item):
+        self.item = item
+
+    def at_scale(self, det, scale, meta):
+        images = self.item["images"][scale][0]
+        meta = {k: v.numpy()[0] for k, v in self.item["meta"][scale].items()}
+        return images, meta
+
+
+def _imread(path):
+    try:
+        import cv2
+    except ImportError:
+        if path.endswith(".npy"):
+            return np.load(path)
+        raise RuntimeError("cv2 is not available here: pass an HxWx3 uint8 numpy array (or a .npy path) to run()")
+    return cv2.imread(path)
 
 
 class BaseDetector(object):
@@ -58,49 +106,46 @@ class BaseDetector(object):
         self.scales = cfg.TEST.TEST_SCALES
         self.cfg = cfg
         self.pause = True
-        self.device_preprocess = True     # HIP warp/normalise kernel for uint8 HxWx3 inputs
-        self.device_postprocess = True    # HIP inverse-affine kernel, one D2H copy of the mapped dets
+
+    # -- geometry of one (image, scale) ----------------------------------------------------------------------------------
+    def input_geometry(self, height, width, scale):
+        """(new_h, new_w, inp_h, inp_w, c, s) of base_detector.py:33-46: the resized image size, the network input size and
+        the centre / extent the affine maps onto it.  FIX_RES: fixed INPUT_H x INPUT_W, longer image side fills it;
+        otherwise the resized image is padded up to the next multiple of PAD + 1 and centred."""
+        cfg = self.cfg
+        new_h, new_w = int(height * scale), int(width * scale)
+        if cfg.TEST.FIX_RES:
+            return (new_h, new_w, cfg.MODEL.INPUT_H, cfg.MODEL.INPUT_W,
+                    np.array([new_w / 2., new_h / 2.], dtype=np.float32), max(height, width) * 1.0)
+        inp_h, inp_w = (new_h | cfg.MODEL.PAD) + 1, (new_w | cfg.MODEL.PAD) + 1
+        return (new_h, new_w, inp_h, inp_w, np.array([new_w // 2, new_h // 2], dtype=np.float32),
+                np.array([inp_w, inp_h], dtype=np.float32))
 
     def pre_process(self, image, scale, meta=None):
-        """base_detector.py:32-62 (image: HxWx3 uint8/float BGR array)."""
+        """base_detector.py:32-62.  image: HxWx3 uint8 BGR host array -> (images float32 [1 or 2,3,inp_h,inp_w] ON THE
+        DEVICE, meta).  cv2.resize + cv2.warpAffine + normalise + transpose (+ flipped twin) run as HIP kernels."""
+        if not (isinstance(image, np.ndarray) and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3):
+            raise _lib.CenterposeHipError("pre_process expects an HxWx3 uint8 array (cv2.imread layout); there is no host fallback")
         height, width = image.shape[0:2]
-        new_height, new_width = int(height * scale), int(width * scale)
-        if self.cfg.TEST.FIX_RES:
-            inp_height, inp_width = self.cfg.MODEL.INPUT_H, self.cfg.MODEL.INPUT_W
-            c = np.array([new_width / 2., new_height / 2.], dtype=np.float32)
-            s = max(height, width) * 1.0
-        else:
-            inp_height = (new_height | self.cfg.MODEL.PAD) + 1
-            inp_width = (new_width | self.cfg.MODEL.PAD) + 1
-            c = np.array([new_width // 2, new_height // 2], dtype=np.float32)
-            s = np.array([inp_width, inp_height], dtype=np.float32)
-        trans_input = get_affine_transform(c, s, 0, [inp_width, inp_height])
-        if (new_height, new_width) != (height, width):     # cv2.resize stand-in: fold the resize into the warp
-            trans_input = trans_input @ np.array([[width / new_width, 0, 0], [0, height / new_height, 0], [0, 0, 1]])
-        if self.device_preprocess and image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3:
-            # SURVEY 8(f1): warp + normalise + HWC->CHW (+ mirrored twin) in one HIP kernel
-            import ctypes
-            Mi = np.ascontiguousarray(np.linalg.inv(np.vstack([trans_input, [0, 0, 1]]))[:2], np.float32)   # out px -> src px
-            img_d = torch.from_numpy(np.ascontiguousarray(image)).cuda()
-            nb = 2 if self.cfg.TEST.FLIP_TEST else 1
-            images = torch.empty((nb, 3, inp_height, inp_width), dtype=torch.float32, device="cuda")
-            mean = np.ascontiguousarray(self.mean.reshape(3), np.float32)
-            std = np.ascontiguousarray(self.std.reshape(3), np.float32)
-            rc = _lib.lib().cp_preprocess_u8_f32(ctypes.c_void_p(img_d.data_ptr()), height, width,
-                                                  Mi.ctypes.data_as(ctypes.c_void_p), _lib.ptr(images), inp_height, inp_width,
-                                                  mean.ctypes.data_as(ctypes.c_void_p), std.ctypes.data_as(ctypes.c_void_p),
-                                                  1 if nb == 2 else 0, _lib.stream())
-            _lib.check(rc, "cp_preprocess_u8_f32")
-        else:
-            inp_image = _warp_affine_bilinear(image, trans_input, inp_width, inp_height)
-            inp_image = ((inp_image / 255. - self.mean) / self.std).astype(np.float32)
-            images = inp_image.transpose(2, 0, 1).reshape(1, 3, inp_height, inp_width)
-            if self.cfg.TEST.FLIP_TEST:
-                images = np.concatenate((images, images[:, :, :, ::-1]), axis=0)
-            images = torch.from_numpy(np.ascontiguousarray(images))
-        meta = {"c": c, "s": s, "out_height": inp_height // self.cfg.MODEL.DOWN_RATIO,
-                "out_width": inp_width // self.cfg.MODEL.DOWN_RATIO}
-        return images, meta
+        new_h, new_w, inp_h, inp_w, c, s = self.input_geometry(height, width, scale)
+        L = _lib.lib()
+        src = torch.from_numpy(np.ascontiguousarray(image)).cuda()
+        if (new_h, new_w) != (height, width):                  # base_detector.py:47 (cv2.resize copies when the size is unchanged)
+            resized = torch.empty((new_h, new_w, 3), dtype=torch.uint8, device="cuda")
+            _lib.check(L.cp_resize_u8(ctypes.c_void_p(src.data_ptr()), height, width, ctypes.c_void_p(resized.data_ptr()),
+                                      new_h, new_w, _lib.stream()), "cp_resize_u8")
+            src = resized
+        trans_input = np.ascontiguousarray(get_affine_transform(c, s, 0, [inp_w, inp_h]), np.float64)
+        nb = 2 if self.cfg.TEST.FLIP_TEST else 1
+        images = torch.empty((nb, 3, inp_h, inp_w), dtype=torch.float32, device="cuda")
+        mean = np.ascontiguousarray(self.mean.reshape(3), np.float32)
+        std = np.ascontiguousarray(self.std.reshape(3), np.float32)
+        _lib.check(L.cp_preprocess_u8_f32(ctypes.c_void_p(src.data_ptr()), new_h, new_w, trans_input.ctypes.data_as(ctypes.c_void_p),
+                                          _lib.ptr(images), inp_h, inp_w, mean.ctypes.data_as(ctypes.c_void_p),
+                                          std.ctypes.data_as(ctypes.c_void_p), 1 if nb == 2 else 0, _lib.stream()),
+                   "cp_preprocess_u8_f32")
+        down = self.cfg.MODEL.DOWN_RATIO
+        return images, {"c": c, "s": s, "out_height": inp_h // down, "out_width": inp_w // down}
 
     def process(self, images, return_time=False):
         raise NotImplementedError
@@ -111,62 +156,32 @@ class BaseDetector(object):
     def merge_outputs(self, detections):
         raise NotImplementedError
 
+    def _source(self, x):
+        if isinstance(x, np.ndarray):
+            return _ArraySource(x)
+        if isinstance(x, str):
+            return _ArraySource(_imread(x))
+        return _PreparedSource(x)
+
     def run(self, image_or_path_or_tensor, meta=None):
-        """base_detector.py:79-140 -- same 7 timing buckets and result dict."""
-        load_time, pre_time, net_time, dec_time, post_time = 0, 0, 0, 0, 0
-        merge_time, tot_time = 0, 0
-        start_time = time.time()
-        pre_processed = False
-        if isinstance(image_or_path_or_tensor, np.ndarray):
-            image = image_or_path_or_tensor
-        elif isinstance(image_or_path_or_tensor, str):
-            image = _imread(image_or_path_or_tensor)
-        else:
-            image = image_or_path_or_tensor["image"][0].numpy()
-            pre_processed_images = image_or_path_or_tensor
-            pre_processed = True
-        loaded_time = time.time()
-        load_time += loaded_time - start_time
-        detections = []
+        """base_detector.py:79-140: every TEST_SCALES entry through pre_process -> process -> post_process, then
+        merge_outputs; returns {'results': {1: rows}, 'tot', 'load', 'pre', 'net', 'dec', 'post', 'merge'}."""
+        clock = StageClock(torch.cuda.synchronize)
+        source = self._source(image_or_path_or_tensor)
+        clock.lap("load", sync=False)
+        per_scale = []
         for scale in self.scales:
-            scale_start_time = time.time()
-            if not pre_processed:
-                images, meta = self.pre_process(image, scale, meta)
-            else:
-                images = pre_processed_images["images"][scale][0]
-                meta = pre_processed_images["meta"][scale]
-                meta = {k: v.numpy()[0] for k, v in meta.items()}
+            images, meta = source.at_scale(self, scale, meta)
             images = images.to(torch.device("cuda"))
-            torch.cuda.synchronize()
-            pre_process_time = time.time()
-            pre_time += pre_process_time - scale_start_time
-            output, dets, forward_time = self.process(images, return_time=True)
-            torch.cuda.synchronize()
-            net_time += forward_time - pre_process_time
-            decode_time = time.time()
-            dec_time += decode_time - forward_time
-            dets = self.post_process(dets, meta, scale)
-            torch.cuda.synchronize()
-            post_process_time = time.time()
-            post_time += post_process_time - decode_time
-            detections.append(dets)
-        results = self.merge_outputs(detections)
-        torch.cuda.synchronize()
-        end_time = time.time()
-        merge_time += end_time - post_process_time
-        tot_time += end_time - start_time
-        return {"results": {1: results}, "tot": tot_time, "load": load_time, "pre": pre_time, "net": net_time,
-                "dec": dec_time, "post": post_time, "merge": merge_time}
-
-
-def _imread(path):
-    try:
-        import cv2
-        return cv2.imread(path)
-    except ImportError:
-        if path.endswith(".npy"):
-            return np.load(path)
-        raise RuntimeError("cv2 is not available here: pass an HxWx3 numpy array (or a .npy path) to run()")
+            clock.lap("pre")
+            _, dets, forward_done = self.process(images, return_time=True)
+            clock.split("net", forward_done)
+            clock.lap("dec")
+            per_scale.append(self.post_process(dets, meta, scale))
+            clock.lap("post")
+        results = self.merge_outputs(per_scale)
+        clock.lap("merge")
+        return clock.report(results)
 
 
 class MultiPoseDetector(BaseDetector):
@@ -209,35 +224,29 @@ class MultiPoseDetector(BaseDetector):
         return outputs, dets
 
     def post_process(self, dets, meta, scale=1):
-        """multi_pose.py:62-71 (batch-1 by construction, like the reference)."""
-        if self.device_postprocess and dets.is_cuda and dets.shape[2] == 56 and self.num_classes == 1:
-            flat = dets.detach().reshape(1, -1, 56).contiguous()
-            trans = get_affine_transform(meta["c"], meta["s"], 0, (meta["out_width"], meta["out_height"]), inv=1)
-            td = torch.from_numpy(np.ascontiguousarray(trans, np.float64)).cuda()
-            out = torch.empty_like(flat)
-            rc = _lib.lib().cp_transform_dets_f32(_lib.ptr(flat), _lib.ptr(out), _lib.c_void_p(td.data_ptr()), 1, flat.shape[1], 17,
-                                                  _lib.c_float(float(scale)), _lib.stream())
-            _lib.check(rc, "cp_transform_dets_f32")
-            return {1: out[0].cpu().numpy()}
-        dets = dets.detach().cpu().numpy().reshape(1, -1, dets.shape[2])
-        dets = multi_pose_post_process(dets.copy(), [meta["c"]], [meta["s"]], meta["out_height"], meta["out_width"])
-        for j in range(1, self.num_classes + 1):
-            dets[0][j] = np.array(dets[0][j], dtype=np.float32).reshape(-1, 56)
-            dets[0][j][:, :4] /= scale
-            dets[0][j][:, 5:39] /= scale
-        return dets[0]
+        """multi_pose.py:62-71 (batch-1 by construction, like the reference): feature-map pixels -> image pixels / scale,
+        {1: float32 [N,56]}.  The per-point Python loop of utils/image.py:19-24 is one HIP kernel."""
+        if self.num_classes != 1 or dets.shape[2] != 56:
+            raise _lib.CenterposeHipError("multi_pose post_process handles one class and 17 joints (dets [..,56])")
+        flat = dets.detach().reshape(1, -1, 56).contiguous()
+        inv = get_affine_transform(meta["c"], meta["s"], 0, (meta["out_width"], meta["out_height"]), inv=1)
+        inv_d = torch.from_numpy(np.ascontiguousarray(inv, np.float64)).cuda()
+        mapped = torch.empty_like(flat)
+        rc = _lib.lib().cp_transform_dets_f32(_lib.ptr(flat), _lib.ptr(mapped), _lib.c_void_p(inv_d.data_ptr()), 1, flat.shape[1], 17,
+                                              _lib.c_float(float(scale)), _lib.stream())
+        _lib.check(rc, "cp_transform_dets_f32")
+        return {1: mapped[0].cpu().numpy()}
 
     def merge_outputs(self, detections):
-        """multi_pose.py:73-79"""
-        results = np.concatenate([detection[1] for detection in detections], axis=0).astype(np.float32)
+        """multi_pose.py:73-79: rows of every scale stacked; soft-NMS when configured or when several scales were run."""
+        rows = np.ascontiguousarray(np.concatenate([d[1] for d in detections], axis=0), dtype=np.float32)
         if self.cfg.TEST.NMS or len(self.cfg.TEST.TEST_SCALES) > 1:
-            soft_nms_39(results, Nt=0.5, method=2)
-        return results.tolist()
+            soft_nms_39(rows, Nt=0.5, method=2)
+        return rows.tolist()
 
 
 def soft_nms_39(boxes, sigma=0.5, Nt=0.3, threshold=0.001, method=0):
     """lib/external/nms.pyx:172-275 -- in place on a float32 [N,56] host array; returns keep list."""
-    import ctypes
     assert boxes.dtype == np.float32 and boxes.flags["C_CONTIGUOUS"] and boxes.ndim == 2 and boxes.shape[1] == 56
     n = ctypes.c_int(0)
     keep = np.zeros(boxes.shape[0], np.int32)

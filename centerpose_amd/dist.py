@@ -35,38 +35,68 @@ def shard_range(global_batch, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_dets(dets, world=None):
+def _shard_sizes(dets, global_batch, world):
+    """Per-rank batch sizes: from the global batch (deterministic, `shard_range`) when the caller knows it, otherwise
+    exchanged on every call -- sizes are never cached across calls, a ragged last global batch must not reuse stale ones."""
+    if global_batch is not None:
+        return [hi - lo for lo, hi in (shard_range(global_batch, r, world) for r in range(world))]
+    sdev = dets.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    sizes = [torch.zeros(1, dtype=torch.int64, device=sdev) for _ in range(world)]
+    dist.all_gather(sizes, torch.tensor([dets.shape[0]], dtype=torch.int64, device=sdev))
+    return [int(s.item()) for s in sizes]
+
+
+def gather_dets(dets, global_batch=None):
     """All-gather detections along the batch axis: [B_local,K,D] -> [sum B_local, K, D] on every rank.
     Equal shard sizes use one all_gather_into_tensor (a single RCCL launch); ragged shards fall back
-    to a padded gather."""
+    to a padded gather.  `global_batch`: the step's global batch when sharded with `shard_range` (no size exchange)."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
         return dets
     world = dist.get_world_size()
     backend = dist.get_backend()
-    sdev = dets.device if backend == "nccl" else torch.device("cpu")
-    sizes = [torch.zeros(1, dtype=torch.int64, device=sdev) for _ in range(world)]
-    mine = torch.tensor([dets.shape[0]], dtype=torch.int64, device=sdev)
-    if getattr(gather_dets, "_equal", None) is None:
-        dist.all_gather(sizes, mine)
-        gather_dets._sizes = [int(s.item()) for s in sizes]
-        gather_dets._equal = len(set(gather_dets._sizes)) == 1
-    if gather_dets._equal and backend == "nccl":
+    if backend == "gloo" and dets.is_cuda:       # gloo has no CUDA all_gather: stage through the host (tests only)
+        return gather_dets(dets.cpu(), global_batch).to(dets.device)
+    sizes = _shard_sizes(dets, global_batch, world)
+    if len(set(sizes)) == 1 and backend == "nccl":
         out = torch.empty((world * dets.shape[0],) + tuple(dets.shape[1:]), dtype=dets.dtype, device=dets.device)
         dist.all_gather_into_tensor(out, dets.contiguous())
         return out
-    if backend == "gloo" and dets.is_cuda:       # gloo has no CUDA all_gather: stage through the host (tests only)
-        return gather_dets(dets.cpu()).to(dets.device)
-    mx = max(gather_dets._sizes)
+    mx = max(sizes)
     pad = dets
     if dets.shape[0] < mx:
         pad = torch.cat([dets, dets.new_zeros((mx - dets.shape[0],) + tuple(dets.shape[1:]))], 0)
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad.contiguous())
-    return torch.cat([p[:n] for p, n in zip(parts, gather_dets._sizes)], 0)
+    return torch.cat([p[:n] for p, n in zip(parts, sizes)], 0)
 
 
-def reset():
-    gather_dets._equal = None
+class DetsGatherer:
+    """The step's one collective on a SIDE stream: `submit(dets)` enqueues the all-gather of this step's
+    detections behind the decode that produced them and returns at once, so the next batch's backbone replay overlaps the
+    (latency-bound, ~358 KB per rank) exchange over xGMI; `collect()` makes the current stream wait for the oldest
+    outstanding gather and returns its [B_global, K, D] tensor.  One step of pipelining; world 1 is a pass-through."""
 
+    def __init__(self, global_batch=None):
+        self.global_batch = global_batch
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.side = torch.cuda.Stream() if self.active and torch.cuda.is_available() and dist.get_backend() == "nccl" else None
+        self.pending = []
 
-gather_dets._equal = None
+    def submit(self, dets):
+        if self.side is None:
+            self.pending.append((gather_dets(dets, self.global_batch) if self.active else dets, None))
+            return
+        self.side.wait_stream(torch.cuda.current_stream())
+        dets.record_stream(self.side)
+        with torch.cuda.stream(self.side):
+            out = gather_dets(dets, self.global_batch)
+            done = torch.cuda.Event()
+            done.record(self.side)
+        self.pending.append((out, done))
+
+    def collect(self):
+        out, done = self.pending.pop(0)
+        if done is not None:
+            torch.cuda.current_stream().wait_event(done)
+            out.record_stream(torch.cuda.current_stream())
+        return out

@@ -9,6 +9,7 @@ allocation and no host synchronisation on the hot path.
 Replaces ``BackBoneWithHead.forward`` (lib/models/model.py:57-59) for dla_34 / res_50 / hrnet.
 """
 import os
+import weakref
 
 import torch
 
@@ -26,25 +27,61 @@ def normalize_state_dict(sd):
     return out
 
 
+class BufferPool:
+    """Activation storage with reuse.  A buffer goes back to the pool when the graph walk drops its last reference to
+    the `Act` that owns it (CPython reference counting: from then on no later launch can name it), and a later
+    activation of a fitting size takes it over.  Launches run in emission order per stream and `Engine.dependencies`
+    turns every reuse into a WAR edge for the multi-stream capture, so reuse never changes results.  DLA-34 at B=16:
+    6.5 GB of one-buffer-per-edge activations -> the live set only.  CP_BUFFER_REUSE=0 gives every edge its own buffer."""
+
+    def __init__(self, device):
+        self.device = device
+        self.reuse = os.environ.get("CP_BUFFER_REUSE", "1") != "0"
+        self.free = []                 # FIFO of idle slots (oldest first: keeps independent branches on different slots)
+        self.bytes = 0                 # device bytes actually allocated
+        self.bytes_requested = 0       # what one-buffer-per-edge would have taken
+
+    def take(self, numel):
+        self.bytes_requested += numel * 4
+        if self.reuse:
+            best = None
+            for i, slot in enumerate(self.free):
+                if numel <= slot.numel() <= 2 * numel and (best is None or slot.numel() < self.free[best].numel()):
+                    best = i
+            if best is not None:
+                return self.free.pop(best)
+        self.bytes += numel * 4
+        return torch.empty((numel,), dtype=torch.float32, device=self.device)
+
+    def give(self, slot):
+        if self.reuse:
+            self.free.append(slot)
+
+
 class PlanBuilder(nets.Graph):
     def __init__(self, sd, B, device, sigmoid_heads=True):
         super().__init__()
         self.sd, self.B, self.dev = sd, B, device
+        self.pool = BufferPool(device)
         if isinstance(sigmoid_heads, bool):
             sigmoid_heads = ("hm", "hm_hp") if sigmoid_heads else ()
         self.sigmoid_heads = tuple(sigmoid_heads)
-        self.launches = []      # (kind, name, algorithmic flops_per_batch, fn); kind 'wino' = 3x3 conv on the Winograd kernel
+        self.launches = []      # (kind, name, algorithmic flops_per_batch, ops.Launch); kind 'wino' = 3x3 conv on the Winograd kernel
         # CP_WINOGRAD=0 keeps every 3x3 on the direct (patch) kernel: A/B switch for tests and profiling
         self.winograd = os.environ.get("CP_WINOGRAD", "1") != "0"
-        self.bytes_alloc = 0
         self._pool_cache = {}
         self.outputs = None
 
+    @property
+    def bytes_alloc(self):
+        return self.pool.bytes
+
     # -- helpers ------------------------------------------------------------------------------
     def buf(self, H, W, C):
-        t = torch.empty((self.B, H, W, C), dtype=torch.float32, device=self.dev)
-        self.bytes_alloc += t.numel() * 4
-        return Act(H, W, C, t)
+        slot = self.pool.take(self.B * H * W * C)
+        act = Act(H, W, C, slot[: self.B * H * W * C].view(self.B, H, W, C))
+        weakref.finalize(act, self.pool.give, slot)       # the walk has dropped the activation: its storage may be reused
+        return act
 
     def w(self, key):
         return self.sd[key].to(self.dev, torch.float32)
@@ -58,8 +95,8 @@ class PlanBuilder(nets.Graph):
             return ops.pack_wino_weight(wp, cin, cout)
         return None
 
-    def add(self, kind, name, flops, fn):
-        self.launches.append((kind, name, flops * self.B, fn))
+    def add(self, kind, name, flops, launch):
+        self.launches.append((kind, name, flops * self.B, launch))
 
     # -- emit hooks ---------------------------------------------------------------------------
     def emit_conv(self, xs, conv, bn, bias, co, k, stride, pad, relu, res, stem):
@@ -70,32 +107,31 @@ class PlanBuilder(nets.Graph):
             # dedicated 7x7 stem kernel (NCHW 3-channel input window staged once in LDS)
             wp7 = ops.pack_stem7_weight(self.w(conv + ".weight"))
             sc7, sh7 = ops.fold_bn(co, self.bn(bn), self.w(conv + ".bias") if bias else None, self.dev)
-            xin, ot7 = xs[0].t, out.t
-            self.add("conv", conv, 2 * Ho * Wo * co * 3 * 49, lambda: ops.stem7x7(xin, wp7, sc7, sh7, ot7, stride, relu))
+            self.add("conv", conv, 2 * Ho * Wo * co * 3 * 49, ops.stem7x7_launch(xs[0].t, wp7, sc7, sh7, out.t, stride, relu))
             return out
         wp = ops.pack_conv_weight(self.w(conv + ".weight"), stem=stem)
         sc, sh = ops.fold_bn(co, self.bn(bn) if bn else None, self.w(conv + ".bias") if bias else None, self.dev)
         srcs = [a.t for a in xs]
         rt = res.t if res is not None else None
         act = ops.ACT_RELU if relu else ops.ACT_NONE
-        ot = out.t
         ci = sum(a.C for a in xs)
         u = None if stem else self.wino(wp, ci, co, k, stride, pad, len(xs))
-
-        def fn():
-            ops.conv2d(srcs, wp, sc, sh, ot, kh=k, kw=k, stride=stride, pad=pad, cout=co, act=act, res=rt, in_nchw=stem,
-                       wino=u)
-        self.add("wino" if u is not None else "conv", conv, 2 * Ho * Wo * co * ci * k * k, fn)
+        self.add("wino" if u is not None else "conv", conv, 2 * Ho * Wo * co * ci * k * k,
+                 ops.conv2d_launch(srcs, wp, sc, sh, out.t, kh=k, kw=k, stride=stride, pad=pad, cout=co, act=act, res=rt,
+                                   in_nchw=stem, wino=u))
         return out
 
     def emit_maxpool(self, x, k, s, p):
+        # a DLA tree pools the same input at every recursion level (pose_dla_dcn.py:197-198,207): emit it once.  Weak
+        # references only -- the cache must neither keep a dead activation's storage out of the pool nor match a
+        # recycled id()
         key = (id(x), k, s, p)
-        if key in self._pool_cache:
-            return self._pool_cache[key]
+        hit = self._pool_cache.get(key)
+        if hit is not None and hit[0]() is x and hit[1]() is not None:
+            return hit[1]()
         out = self.buf((x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1, x.C)
-        xt, ot = x.t, out.t
-        self.add("pool", "maxpool%dx%d" % (k, k), 0, lambda: ops.maxpool2d(xt, ot, k, s, p))
-        self._pool_cache[key] = out
+        self.add("pool", "maxpool%dx%d" % (k, k), 0, ops.maxpool2d_launch(x.t, out.t, k, s, p))
+        self._pool_cache[key] = (weakref.ref(x), weakref.ref(out))
         return out
 
     def emit_dcn(self, x, name, co):
@@ -106,44 +142,35 @@ class PlanBuilder(nets.Graph):
         out = self.buf(x.H, x.W, co)
         wp = ops.pack_conv_weight(self.w(name + ".conv.weight"))
         sc, sh = ops.fold_bn(co, self.bn(name + ".actf.0"), self.w(name + ".conv.bias"), self.dev)
-        xt, omt, ot = x.t, om.t, out.t
         uom = self.wino(wom, x.C, 32)
-
-        def fn_om():
-            ops.conv2d([xt], wom, som, hom, omt, kh=3, kw=3, stride=1, pad=1, cout=32, wino=uom)
-
-        def fn():
-            ops.dcn_v2(xt, omt, wp, sc, sh, ot, cout=co, om_sigmoid=True, act=ops.ACT_RELU)
-        self.add("wino" if uom is not None else "conv", name + ".conv.conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9, fn_om)
-        self.add("dcn", name + ".conv", 2 * x.H * x.W * co * x.C * 9, fn)
+        self.add("wino" if uom is not None else "conv", name + ".conv.conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9,
+                 ops.conv2d_launch([x.t], wom, som, hom, om.t, kh=3, kw=3, stride=1, pad=1, cout=32, wino=uom))
+        self.add("dcn", name + ".conv", 2 * x.H * x.W * co * x.C * 9,
+                 ops.dcn_v2_launch(x.t, om.t, wp, sc, sh, out.t, cout=co, om_sigmoid=True, act=ops.ACT_RELU))
         return out
 
     def emit_up_add(self, x, wname, f, add):
         out = self.buf(x.H * f, x.W * f, x.C)
         wk = ops.pack_dw_deconv_weight(self.w(wname + ".weight"))
-        xt, at, ot = x.t, add.t, out.t
-        self.add("up", wname, 2 * out.H * out.W * x.C * 4, lambda: ops.dw_deconv_add(xt, wk, at, ot, f))
+        self.add("up", wname, 2 * out.H * out.W * x.C * 4, ops.dw_deconv_add_launch(x.t, wk, add.t, out.t, f))
         return out
 
     def emit_deconv4(self, x, wname, bn, co):
         out = self.buf(x.H * 2, x.W * 2, co)
         w = self.w(wname + ".weight")
         sc, sh = ops.fold_bn(co, self.bn(bn), None, self.dev)
-        xt, ot, H, W = x.t, out.t, x.H, x.W
+        H, W = x.H, x.W
         # the four sub-pixel 2x2 convolutions in ONE launch (sub g = py*2+px): 4x the blocks - a 2048 -> 256 deconv at
         # 16x16 is otherwise 4 x 128 blocks of 512 k-steps each on 256 CUs
         wp = torch.cat([ops.pack_deconv4_subpixel(w, py, px) for py in range(2) for px in range(2)], 0).contiguous()
-
-        def fn():
-            ops.conv2d([xt], wp, sc, sh, ot, kh=2, kw=2, stride=1, pad=0, pad_yx=(1, 1), cout=co, act=ops.ACT_RELU, Ho=H, Wo=W,
-                       out_scatter=(2, 2, 0, 0), nsub=4)
-        self.add("conv", wname, 4 * 2 * H * W * co * x.C * 4, fn)
+        self.add("conv", wname, 4 * 2 * H * W * co * x.C * 4,
+                 ops.conv2d_launch([x.t], wp, sc, sh, out.t, kh=2, kw=2, stride=1, pad=0, pad_yx=(1, 1), cout=co, act=ops.ACT_RELU,
+                                   Ho=H, Wo=W, out_scatter=(2, 2, 0, 0), nsub=4))
         return out
 
     def emit_sum_up(self, xs, shifts, relu):
         out = self.buf(xs[0].H, xs[0].W, xs[0].C)
-        ts, ot = [a.t for a in xs], out.t
-        self.add("sum", "fuse", 0, lambda: ops.sum_up(ts, shifts, ot, relu))
+        self.add("sum", "fuse", 0, ops.sum_up_launch([a.t for a in xs], shifts, out.t, relu))
         return out
 
     def emit_head(self, feat, p, hc):
@@ -157,19 +184,15 @@ class PlanBuilder(nets.Graph):
         outs = []
         if per_head:
             mid = self.buf(H, W, hc)
-            mt = mid.t
         else:
             mid = self.buf(H, W, 6 * hc)
-            mt = mid.t
             w3 = torch.cat([self.w("%s.%s.0.weight" % (p, h)) for h, _ in nets.HEADS], 0)
             b3 = torch.cat([self.w("%s.%s.0.bias" % (p, h)) for h, _ in nets.HEADS], 0)
             wp3 = ops.pack_conv_weight(w3)
             sc3, sh3 = ops.fold_bn(6 * hc, None, b3, self.dev)
             u3 = self.wino(wp3, feat.C, 6 * hc)
-
-            def fn3():
-                ops.conv2d([ft], wp3, sc3, sh3, mt, kh=3, kw=3, stride=1, pad=1, cout=6 * hc, act=ops.ACT_RELU, wino=u3)
-            self.add("wino" if u3 is not None else "conv", p + ".*.0", 2 * H * W * 6 * hc * feat.C * 9, fn3)
+            self.add("wino" if u3 is not None else "conv", p + ".*.0", 2 * H * W * 6 * hc * feat.C * 9,
+                     ops.conv2d_launch([ft], wp3, sc3, sh3, mid.t, kh=3, kw=3, stride=1, pad=1, cout=6 * hc, act=ops.ACT_RELU, wino=u3))
         for i, (h, n) in enumerate(nets.HEADS):
             o = torch.empty((self.B, n, H, W), dtype=torch.float32, device=self.dev)
             wp = ops.pack_conv_weight(self.w("%s.%s.2.weight" % (p, h)))
@@ -179,17 +202,14 @@ class PlanBuilder(nets.Graph):
                 wp3h = ops.pack_conv_weight(self.w("%s.%s.0.weight" % (p, h)))
                 sc3h, sh3h = ops.fold_bn(hc, None, self.w("%s.%s.0.bias" % (p, h)), self.dev)
                 u3h = self.wino(wp3h, feat.C, hc)
-
-                def fn3h(wp3h=wp3h, sc3h=sc3h, sh3h=sh3h, u3h=u3h):
-                    ops.conv2d([ft], wp3h, sc3h, sh3h, mt, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU, wino=u3h)
-                self.add("wino" if u3h is not None else "conv", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9, fn3h)
-                sl = mt
+                self.add("wino" if u3h is not None else "conv", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9,
+                         ops.conv2d_launch([ft], wp3h, sc3h, sh3h, mid.t, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU,
+                                           wino=u3h))
+                sl = mid.t
             else:
-                sl = mt[..., i * hc:(i + 1) * hc]
-
-            def fn(sl=sl, wp=wp, sc=sc, sh=sh, o=o, n=n, act=act):
-                ops.conv2d([sl], wp, sc, sh, o, kh=1, kw=1, cout=n, act=act, out_nchw=True)
-            self.add("conv", "%s.%s.2" % (p, h), 2 * H * W * n * hc, fn)
+                sl = mid.t[..., i * hc:(i + 1) * hc]
+            self.add("conv", "%s.%s.2" % (p, h), 2 * H * W * n * hc,
+                     ops.conv2d_launch([sl], wp, sc, sh, o, kh=1, kw=1, cout=n, act=act, out_nchw=True))
             outs.append(o)
         self.outputs = outs
         return outs
@@ -239,42 +259,32 @@ class Engine:
 
     # -- execution ------------------------------------------------------------------------------
     def run_eager(self):
-        for _, _, _, fn in self.launches:
-            fn()
+        for _, _, _, launch in self.launches:
+            launch.run()
 
     def dependencies(self):
-        """Data dependencies of the launch schedule, from the recorded launch arguments: for every launch the indices
-        of earlier launches it must follow (RAW on its inputs, WAW / WAR on its output), per storage."""
-        from . import plan
+        """Data dependencies of the launch schedule: for every launch the indices of earlier launches it must follow
+        (RAW on its inputs, WAW / WAR on its output), per storage -- buffer reuse shows up here as WAR edges."""
         deps = []
         last_writer, readers = {}, {}
-        with torch.cuda.device(self.device):
-            for i, (_, _, _, fn) in enumerate(self.launches):
-                with plan._Recorder() as rec:
-                    fn()
-                rd, wr = set(), set()
-                for _, args in rec.calls:
-                    for key, v in args.items():
-                        ts = v if isinstance(v, (list, tuple)) else [v]
-                        for t in ts:
-                            if isinstance(t, torch.Tensor):
-                                (wr if key == plan.OUT_PARAM else rd).add(t.untyped_storage().data_ptr())
-                d = set()
-                for k in rd:
-                    if k in last_writer:
-                        d.add(last_writer[k])
-                for k in wr:
-                    if k in last_writer:
-                        d.add(last_writer[k])
-                    d.update(readers.get(k, ()))
-                d.discard(i)
-                for k in rd:
-                    readers.setdefault(k, []).append(i)
-                for k in wr:
-                    last_writer[k] = i
-                    readers[k] = []
-                deps.append(sorted(d))
-            torch.cuda.synchronize(self.device)
+        for i, (_, _, _, launch) in enumerate(self.launches):
+            rd = {t.untyped_storage().data_ptr() for t in launch.reads}
+            wr = {launch.out.untyped_storage().data_ptr()}
+            d = set()
+            for k in rd:
+                if k in last_writer:
+                    d.add(last_writer[k])
+            for k in wr:
+                if k in last_writer:
+                    d.add(last_writer[k])
+                d.update(readers.get(k, ()))
+            d.discard(i)
+            for k in rd:
+                readers.setdefault(k, []).append(i)
+            for k in wr:
+                last_writer[k] = i
+                readers[k] = []
+            deps.append(sorted(d))
         return deps
 
     def _run_branches(self, main, nstreams, deps):
@@ -293,7 +303,7 @@ class Engine:
         fork.record(main)
         joined = [True] + [False] * (len(streams) - 1)
         waited = [[-1] * len(streams) for _ in streams]      # waited[s][t]: youngest launch of stream t that s has waited for
-        for i, (_, _, _, fn) in enumerate(self.launches):
+        for i, (_, _, _, launch) in enumerate(self.launches):
             # continue the chain of a predecessor that is still the tail of its stream; otherwise take an idle stream
             sidx = None
             for j in sorted(deps[i], reverse=True):
@@ -318,7 +328,7 @@ class Engine:
                     st.wait_event(events[j])
                     waited[sidx][t] = j
             with torch.cuda.stream(st):
-                fn()
+                launch.run()
             ev = torch.cuda.Event()
             ev.record(st)
             events[i], where[i], tail[sidx] = ev, sidx, i
@@ -344,7 +354,7 @@ class Engine:
         nstreams = getattr(self, "nstreams", None) or int(os.environ.get("CP_STREAMS", "2"))
         g = None
         if nstreams > 1:
-            deps = self.dependencies()           # runs every launch once: must happen outside the capture
+            deps = self.dependencies()
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
@@ -379,38 +389,48 @@ class Engine:
     __call__ = forward
 
     def launch_bytes(self):
-        """Algorithmic (compulsory) HBM bytes of every launch: each tensor argument once - inputs, residual, the weights
-        the kernel actually reads, output.  Taken from the recorded launch arguments (plan._Recorder), so it follows
-        whatever the plan builder emitted."""
-        from . import plan
-        out = []
-        with torch.cuda.device(self.device):
-            for kind, _, _, fn in self.launches:
-                with plan._Recorder() as rec:
-                    fn()
-                n = 0
-                for _, args in rec.calls:
-                    for key, v in args.items():
-                        if (key == "wp" and args.get("wino") is not None) or v is None:
-                            continue                      # Winograd launches read U, not the direct weights
-                        ts = v if isinstance(v, (list, tuple)) else [v]
-                        n += sum(4 * t.numel() for t in ts if isinstance(t, torch.Tensor))
-                out.append(n)
-            torch.cuda.synchronize(self.device)
-        return out
+        """Algorithmic (compulsory) HBM bytes of every launch: each tensor argument once -- inputs, residual, the weights
+        the kernel actually reads (Winograd launches carry U, not the direct weights), output."""
+        return [sum(4 * t.numel() for t in launch.tensors if t is not None) for _, _, _, launch in self.launches]
 
     def profile(self, iters=5):
-        """Per-launch timing with HIP events on the launch stream -> list of dicts (kind, name, flops, bytes, ms)."""
+        """Per-launch timing, every launch repeated `iters` times back to back (cache-hot: an optimistic number,
+        use `profile_in_sequence` for what a launch costs inside a step) -> list of dicts."""
         torch.cuda.synchronize(self.device)
         self.run_eager()
         nbytes = self.launch_bytes()
         recs = []
-        for (kind, name, flops, fn), nb in zip(self.launches, nbytes):
+        for (kind, name, flops, launch), nb in zip(self.launches, nbytes):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(iters):
-                fn()
+                launch.run()
             e1.record()
             e1.synchronize()
-            recs.append(dict(kind=kind, name=name, flops=flops, bytes=nb, ms=e0.elapsed_time(e1) / iters))
+            recs.append(dict(kind=kind, name=name, fn=launch.fn, flops=flops, bytes=nb, ms=e0.elapsed_time(e1) / iters))
+        return recs
+
+    def profile_in_sequence(self, iters=10):
+        """Per-launch timing INSIDE the step: the whole schedule runs in order on one stream with a HIP event between
+        consecutive launches, `iters` times; a launch's time is the median over the passes of (event after - event
+        before), so every kernel sees the caches the previous launches of the step leave behind (what rocprofv3
+        --kernel-trace reports for the captured graph, to within the event overhead)."""
+        torch.cuda.synchronize(self.device)
+        self.run_eager()
+        n = len(self.launches)
+        samples = [[] for _ in range(n)]
+        for _ in range(iters):
+            evs = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+            evs[0].record()
+            for i, (_, _, _, launch) in enumerate(self.launches):
+                launch.run()
+                evs[i + 1].record()
+            evs[n].synchronize()
+            for i in range(n):
+                samples[i].append(evs[i].elapsed_time(evs[i + 1]))
+        nbytes = self.launch_bytes()
+        recs = []
+        for (kind, name, flops, launch), nb, sm in zip(self.launches, nbytes, samples):
+            sm.sort()
+            recs.append(dict(kind=kind, name=name, fn=launch.fn, flops=flops, bytes=nb, ms=sm[len(sm) // 2]))
         return recs

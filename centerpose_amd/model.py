@@ -3,6 +3,9 @@
 (:122-131), ``BackBoneWithHead`` (:44-59).  The "module" is a holder of a reference-format
 state_dict plus a cache of compiled inference plans (engine.Engine) per input shape; forward runs
 the fused HIP schedule.  Weight loading / orchestration stays Python, compute does not."""
+import os
+from collections import OrderedDict
+
 import torch
 
 from . import engine, nets, synth
@@ -20,7 +23,11 @@ class BackBoneWithHead:
         self._sd = synth.make_state_dict(self.arch, seed=getattr(cfg, "SEED", 317) if cfg is not None else 317,
                                          head_conv=head_conv)
         self.device = torch.device("cuda")
-        self._engines = {}
+        # compiled plans per input shape, least recently used first.  FIX_RES = false (dla_34 / hrnet yamls) makes every
+        # distinct image size a new shape: the cache is bounded (CP_ENGINE_CACHE, default 4) and an evicted plan's
+        # buffers, constants and hipGraph are released, so an evaluate.py-style loop over COCO does not grow.
+        self._engines = OrderedDict()
+        self.max_engines = max(1, int(os.environ.get("CP_ENGINE_CACHE", "4")))
         self.use_graph = True
 
     # -- nn.Module-ish surface used by the detector --------------------------------------------
@@ -44,11 +51,16 @@ class BackBoneWithHead:
 
     def engine_for(self, B, H, W):
         key = (B, H, W)
-        if key not in self._engines:
-            self._engines[key] = engine.Engine(self.arch, self._sd, B, H, W, device=self.device,
-                                               head_conv=self.head_conv, sigmoid_heads=("hm",) + (("hm_hp",) if self.sigmoid_hm_hp else ()),
-                                               use_graph=self.use_graph)
-        return self._engines[key]
+        eng = self._engines.get(key)
+        if eng is not None:
+            self._engines.move_to_end(key)
+            return eng
+        while len(self._engines) >= self.max_engines:
+            self._engines.popitem(last=False)            # drop the least recently used plan before building the next one
+        eng = engine.Engine(self.arch, self._sd, B, H, W, device=self.device, head_conv=self.head_conv,
+                            sigmoid_heads=("hm",) + (("hm_hp",) if self.sigmoid_hm_hp else ()), use_graph=self.use_graph)
+        self._engines[key] = eng
+        return eng
 
     def forward(self, x):
         """x: float32 NCHW on the HIP device.  Returns the reference's list

@@ -22,7 +22,7 @@ ARCH_HEAD = {"dla_34": (64, 256), "res_50": (256, 64), "hrnet": (32, 64)}
 
 class Act:
     """A feature map in the plan: NHWC, [B,H,W,C]; ``t`` is the device tensor (None in spec mode)."""
-    __slots__ = ("H", "W", "C", "t")
+    __slots__ = ("H", "W", "C", "t", "__weakref__")      # weak-referenceable: engine.BufferPool reclaims a dead activation's storage
 
     def __init__(self, H, W, C, t=None):
         self.H, self.W, self.C, self.t = H, W, C, t

@@ -31,6 +31,67 @@ def round_up(x, m):
     return (x + m - 1) // m * m
 
 
+class Launch:
+    """One enqueue of a C-ABI kernel entry point with everything resolved at plan time: the C function, its descriptor
+    struct (or None), the tensor arguments in C order (None = NULL) and the integer arguments.  `run()` only passes
+    cached device pointers and the current stream.  The same record is what `plan.py` serialises and what the C plan
+    runtime (csrc/plan_runtime.cpp, `cp_plan_*`) replays -- `FN_SIGNATURES` is the contract between the three."""
+    __slots__ = ("fn", "desc", "tensors", "ints", "out_index", "_cfn", "_args")
+
+    def __init__(self, fn, desc, tensors, ints=(), out_index=-1):
+        self.fn, self.desc, self.tensors, self.ints = fn, desc, list(tensors), [int(i) for i in ints]
+        self.out_index = out_index % len(self.tensors)
+        self._cfn = None
+        self._args = None
+
+    @property
+    def out(self):
+        return self.tensors[self.out_index]
+
+    @property
+    def reads(self):
+        return [t for i, t in enumerate(self.tensors) if t is not None and i != self.out_index]
+
+    def bind(self):
+        """Resolve the C symbol and the argument list once (device pointers are stable: plan buffers never move)."""
+        L = _lib.lib()
+        self._cfn = getattr(L, self.fn)
+        ptrs = [_lib.vptr(t) if t is not None else _lib.c_void_p(0) for t in self.tensors]
+        self._args = marshal(self.fn, self.desc, ptrs, self.ints)
+
+    def run(self):
+        if self._cfn is None:
+            self.bind()
+        _lib.check(self._cfn(*self._args, _lib.stream()), self.fn)
+
+
+def marshal(fn, desc, ptrs, ints):
+    """C argument list (without the trailing stream) of entry point `fn` from the flat (desc, ptrs, ints) record.
+    Mirrors the switch in csrc/plan_runtime.cpp::run_op."""
+    d = ctypes.byref(desc) if desc is not None else None
+    if fn == "cp_conv2d_f32":                     # ptrs: src0..src3, w, scale, shift, res, out
+        srcs = (ctypes.c_void_p * 4)(*[p.value for p in ptrs[:4]])
+        return [d, srcs] + ptrs[4:]
+    if fn in ("cp_conv3x3_winograd_f32", "cp_dcn_v2_f32"):      # desc + pointers in order
+        return [d] + ptrs
+    if fn == "cp_stem7x7_f32":                    # ptrs: x, w, scale, shift, out; ints: B, H, W, Cout, stride, outLd, relu
+        return ptrs + ints
+    if fn == "cp_maxpool2d_nhwc_f32":             # ptrs: in, out; ints: inLd, outLd, B, H, W, C, k, s, p
+        return [ptrs[0], ints[0], ptrs[1]] + ints[1:]
+    if fn == "cp_dw_deconv_add_nhwc_f32":         # ptrs: in, w, add, out; ints: inLd, addLd, outLd, B, H, W, C, f
+        return [ptrs[0], ints[0], ptrs[1], ptrs[2], ints[1], ptrs[3]] + ints[2:]
+    if fn == "cp_sum_up_nhwc_f32":                # ptrs: src0..src3, out; ints: n, ld0..3, shift0..3, outLd, B, H, W, C, relu
+        srcs = (ctypes.c_void_p * 4)(*[p.value for p in ptrs[:4]])
+        lds = (ctypes.c_int * 4)(*ints[1:5])
+        shs = (ctypes.c_int * 4)(*ints[5:9])
+        return [ints[0], srcs, lds, shs, ptrs[4]] + ints[9:]
+    raise ValueError("unknown launch function %r" % fn)
+
+
+FN_IDS = {"cp_conv2d_f32": 1, "cp_conv3x3_winograd_f32": 2, "cp_dcn_v2_f32": 3, "cp_stem7x7_f32": 4,
+          "cp_maxpool2d_nhwc_f32": 5, "cp_dw_deconv_add_nhwc_f32": 6, "cp_sum_up_nhwc_f32": 7}
+
+
 def pad_rows(t, ldw):
     """[Co, K] -> [ldw, K] zero padded, contiguous (n-major packed weights)."""
     Co, K = t.shape
@@ -92,8 +153,14 @@ def _ld(t):
     return t.stride(2)
 
 
-def conv2d(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=ACT_NONE, res=None, out_nchw=False,
-           in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0, wino=None, nsub=1):
+def conv2d(srcs, wp, scale, shift, out, **kw):
+    """Enqueue `conv2d_launch(...)` now (eager use: tests, tools)."""
+    conv2d_launch(srcs, wp, scale, shift, out, **kw).run()
+    return out
+
+
+def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=ACT_NONE, res=None, out_nchw=False,
+                  in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0, wino=None, nsub=1):
     """Fused conv: out = act((sum_src conv(src)) * scale + shift [+ res]).
 
     nsub = 4: the four sub-pixel 2x2 convs of a dense ConvTranspose2d(k4,s2,p1) in one launch; wp = [4*ldw, K] (sub g = py*2+px),
@@ -104,7 +171,6 @@ def conv2d(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=AC
     srcs: list of NHWC tensors (concatenated along C) or one NCHW tensor when in_nchw.
     out : NHWC [B,OH,OW,>=cout] (or NCHW [B,cout,OH,OW] when out_nchw).
     out_scatter = (osy, osx, ooy, oox): output pixel (oy*osy+ooy, ox*osx+oox) (sub-pixel deconv)."""
-    L = _lib.lib()
     d = ConvDesc()
     d.nsrc = len(srcs)
     if in_nchw:
@@ -134,17 +200,12 @@ def conv2d(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=AC
         d.OH, d.OW, d.outLd = out.shape[1], out.shape[2], _ld(out)
     d.osy, d.osx, d.ooy, d.oox = out_scatter if out_scatter is not None else (1, 1, 0, 0)
     d.act, d.inNCHW, d.tile = act, 1 if in_nchw else 0, tile
+    for t in (wp, scale, shift, wino):
+        assert t is None or t.is_contiguous()
     if wino is not None:
         assert len(srcs) == 1 and not in_nchw
-        rc = L.cp_conv3x3_winograd_f32(ctypes.byref(d), _lib.vptr(srcs[0]), _lib.ptr(wino), _lib.ptr(scale),
-                                       _lib.ptr(shift), _lib.vptr(res), _lib.vptr(out), _lib.stream())
-        _lib.check(rc, "cp_conv3x3_winograd_f32")
-        return out
-    ptrs = (ctypes.c_void_p * 4)(*[_lib.vptr(s).value for s in srcs] + [None] * (4 - len(srcs)))
-    rc = L.cp_conv2d_f32(ctypes.byref(d), ptrs, _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift),
-                         _lib.vptr(res), _lib.vptr(out), _lib.stream())
-    _lib.check(rc, "cp_conv2d_f32")
-    return out
+        return Launch("cp_conv3x3_winograd_f32", d, [srcs[0], wino, scale, shift, res, out])
+    return Launch("cp_conv2d_f32", d, list(srcs) + [None] * (4 - len(srcs)) + [wp, scale, shift, res, out])
 
 
 def wino_eligible(cin, k, stride, pad, nsrc=1):
@@ -166,10 +227,14 @@ def pack_wino_weight(wp, cin, cout):
     return u
 
 
-def dcn_v2(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, pad=1, dil=1, om_sigmoid=True,
-           act=ACT_NONE, out_nchw=False, tile=0):
+def dcn_v2(x, om, wp, scale, shift, out, **kw):
+    dcn_v2_launch(x, om, wp, scale, shift, out, **kw).run()
+    return out
+
+
+def dcn_v2_launch(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, pad=1, dil=1, om_sigmoid=True,
+                  act=ACT_NONE, out_nchw=False, tile=0):
     """Fused DCNv2: x NHWC [B,H,W,C]; om NHWC [B,Ho,Wo,>=3*kh*kw] (dy,dx pairs then mask)."""
-    L = _lib.lib()
     B, H, W, C = x.shape
     d = DcnDesc()
     Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
@@ -182,17 +247,16 @@ def dcn_v2(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, pad=1, d
     d.outNCHW = 1 if out_nchw else 0
     d.outLd = 0 if out_nchw else _ld(out)
     d.act, d.tile = act, tile
-    rc = L.cp_dcn_v2_f32(ctypes.byref(d), _lib.vptr(x), _lib.vptr(om), _lib.ptr(wp), _lib.ptr(scale),
-                         _lib.ptr(shift), _lib.vptr(out), _lib.stream())
-    _lib.check(rc, "cp_dcn_v2_f32")
-    return out
+    return Launch("cp_dcn_v2_f32", d, [x, om, wp, scale, shift, out])
+
+
+def maxpool2d_launch(x, out, k, s, p):
+    B, H, W, C = x.shape
+    return Launch("cp_maxpool2d_nhwc_f32", None, [x, out], [_ld(x), _ld(out), B, H, W, C, k, s, p])
 
 
 def maxpool2d(x, out, k, s, p):
-    B, H, W, C = x.shape
-    rc = _lib.lib().cp_maxpool2d_nhwc_f32(_lib.vptr(x), _ld(x), _lib.vptr(out), _ld(out), B, H, W, C, k, s, p,
-                                          _lib.stream())
-    _lib.check(rc, "cp_maxpool2d_nhwc_f32")
+    maxpool2d_launch(x, out, k, s, p).run()
     return out
 
 
@@ -202,24 +266,27 @@ def pack_dw_deconv_weight(w):
     return w.reshape(C, k * k).t().contiguous().float()
 
 
-def dw_deconv_add(x, wk, add, out, f):
+def dw_deconv_add_launch(x, wk, add, out, f):
     B, H, W, C = x.shape
-    rc = _lib.lib().cp_dw_deconv_add_nhwc_f32(_lib.vptr(x), _ld(x), _lib.ptr(wk), _lib.vptr(add),
-                                              _ld(add) if add is not None else 0, _lib.vptr(out), _ld(out), B, H, W, C,
-                                              f, _lib.stream())
-    _lib.check(rc, "cp_dw_deconv_add_nhwc_f32")
+    assert wk.is_contiguous()
+    return Launch("cp_dw_deconv_add_nhwc_f32", None, [x, wk, add, out],
+                  [_ld(x), _ld(add) if add is not None else 0, _ld(out), B, H, W, C, f])
+
+
+def dw_deconv_add(x, wk, add, out, f):
+    dw_deconv_add_launch(x, wk, add, out, f).run()
     return out
 
 
-def sum_up(srcs, shifts, out, relu):
+def sum_up_launch(srcs, shifts, out, relu):
     B, H, W, C = out.shape
     n = len(srcs)
-    ptrs = (ctypes.c_void_p * 4)(*[_lib.vptr(s).value for s in srcs] + [None] * (4 - n))
-    lds = (ctypes.c_int * 4)(*[_ld(s) for s in srcs] + [0] * (4 - n))
-    shs = (ctypes.c_int * 4)(*list(shifts) + [0] * (4 - n))
-    rc = _lib.lib().cp_sum_up_nhwc_f32(n, ptrs, lds, shs, _lib.vptr(out), _ld(out), B, H, W, C, 1 if relu else 0,
-                                       _lib.stream())
-    _lib.check(rc, "cp_sum_up_nhwc_f32")
+    return Launch("cp_sum_up_nhwc_f32", None, list(srcs) + [None] * (4 - n) + [out],
+                  [n] + [_ld(s) for s in srcs] + [0] * (4 - n) + list(shifts) + [0] * (4 - n) + [_ld(out), B, H, W, C, 1 if relu else 0])
+
+
+def sum_up(srcs, shifts, out, relu):
+    sum_up_launch(srcs, shifts, out, relu).run()
     return out
 
 
@@ -267,11 +334,13 @@ def pack_stem7_weight(w):
     return wp.reshape(Co, 176).contiguous()
 
 
-def stem7x7(x, wp, scale, shift, out, stride, relu=True):
+def stem7x7_launch(x, wp, scale, shift, out, stride, relu=True):
     """7x7 / pad 3 stem on the NCHW 3-channel input -> NHWC out."""
     B, C, H, W = x.shape
-    assert C == 3 and x.is_contiguous()
-    rc = _lib.lib().cp_stem7x7_f32(_lib.ptr(_lib.f32(x)), _lib.ptr(wp), _lib.ptr(scale), _lib.ptr(shift), _lib.vptr(out), B, H, W,
-                                   wp.shape[0], stride, _ld(out), 1 if relu else 0, _lib.stream())
-    _lib.check(rc, "cp_stem7x7_f32")
+    assert C == 3 and x.is_contiguous() and wp.is_contiguous()
+    return Launch("cp_stem7x7_f32", None, [x, wp, scale, shift, out], [B, H, W, wp.shape[0], stride, _ld(out), 1 if relu else 0])
+
+
+def stem7x7(x, wp, scale, shift, out, stride, relu=True):
+    stem7x7_launch(x, wp, scale, shift, out, stride, relu).run()
     return out

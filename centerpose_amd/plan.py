@@ -1,57 +1,49 @@
-"""On-disk plan format (SURVEY.md section 8, row f4): the checkpoint -> plan compiler's output as a file.
+"""On-disk plan format (SURVEY.md section 8, row f4 / 8b item 3): the checkpoint -> plan compiler's output as a file.
 
 `model.py:67-131` of the reference re-reads a training checkpoint at every start.  Here the expensive part of start-up
 is the plan compilation (`engine.PlanBuilder`): BN folding, weight re-packing to the kernels' fragment orders, the
-Winograd weight transform and the launch schedule.  `save_plan` records an `engine.Engine`'s launch schedule by running it
-once with the launch functions of `ops` wrapped, and writes
+Winograd weight transform and the launch schedule.  A plan file holds exactly what `engine.Engine` runs -- its list of
+`ops.Launch` records (C entry point, descriptor struct bytes, tensor arguments, integer arguments) plus the constants
+they name -- in a flat little-endian binary layout with no pickled objects, so that the same file is read by
 
-    {"format": "centerpose_amd.plan", "version": 1,
-     "meta":    {arch, batch, height, width, flops_per_image, abi},
-     "buffers": [numel, ...]                       activation / output storages (float32 elements), allocated at load
-     "consts":  [tensor, ...]                      packed weights, folded scale/shift, Winograd U (CPU, contiguous)
-     "input":   view,  "outputs": [view, ...]      view = ("buf", id, offset, shape, stride) | ("const", id)
-     "ops":     [{"kind", "name", "flops", "fn", "args": {param: view | scalar | [..]}}, ...]}
+  * `load_plan` (Python, below): rebuilds an `engine.Engine` without checkpoint parsing or packing;
+  * `cp_plan_load` (C ABI, csrc/plan_runtime.cpp): a C/C++ caller runs the network with no Python at all.
 
-with `torch.save` (tensors in the zip container, everything else plain Python).  `load_plan` allocates the buffers, moves
-the constants to the device and rebuilds the closures: no checkpoint, no `nets` walk, no packing.  The schedule is the one
-the engine ran, so outputs are bit-identical (tests/test_engine_hip.py::test_plan_roundtrip).
+Layout (all integers little-endian; offsets in bytes from the start of the file):
+
+    char[8]  magic "CPPLAN02"
+    u32      abi            cp_abi_version() of the library that wrote it (descriptor struct layouts)
+    u32      B, H, W        network input [B,3,H,W]
+    u32      nbuf, nconst, nops, nout
+    u32      meta_len       JSON (utf-8): {"arch", "flops_per_image", "ops": [{"kind", "name", "flops"}, ...]}
+    u32      0              (pads the fixed header to 48 bytes: everything below is 8-byte aligned)
+    u8[meta_len], zero padded to a multiple of 8
+    u64[nbuf]               activation / output storages, float32 elements (allocated at load time)
+    {u64 numel, u64 offset}[nconst]      packed weights, folded scale/shift, Winograd U: raw float32 at `offset`
+    ref                     network input
+    {ref, u32[4] shape}[nout]            head outputs (NCHW)
+    op[nops]:  u32 fn, u32 desc_bytes, u32 nptr, u32 nint, u32 out_index, u32 0,
+               u8[desc_bytes] zero padded to 8, ref[nptr], i32[nint] zero padded to 8
+    ... constant data, each block 64-byte aligned
+    ref = {u32 kind (0 NULL, 1 buffer, 2 constant), u32 id, u64 offset (floats), u64 numel}
 """
-import inspect
+import ctypes
+import json
+import struct
 
+import numpy as np
 import torch
 
 from . import _lib, ops
 
-FORMAT, VERSION = "centerpose_amd.plan", 1
-# the engine's launch functions: every `ops` entry point that enqueues kernels from a plan
-LAUNCH_FNS = ("conv2d", "dcn_v2", "stem7x7", "maxpool2d", "dw_deconv_add", "sum_up")
-OUT_PARAM = "out"
+MAGIC = b"CPPLAN02"
+REF_NULL, REF_BUF, REF_CONST = 0, 1, 2
+FN_NAMES = {v: k for k, v in ops.FN_IDS.items()}
+DESC_TYPES = {"cp_conv2d_f32": ops.ConvDesc, "cp_conv3x3_winograd_f32": ops.ConvDesc, "cp_dcn_v2_f32": ops.DcnDesc}
 
 
-class _Recorder:
-    """Wraps the launch functions of `ops`; every call is appended as (fn name, bound arguments)."""
-
-    def __init__(self):
-        self.calls = []
-        self._saved = {}
-
-    def __enter__(self):
-        for name in LAUNCH_FNS:
-            real = getattr(ops, name)
-            self._saved[name] = real
-            sig = inspect.signature(real)
-
-            def wrapper(*a, __real=real, __sig=sig, __name=name, **k):
-                bound = __sig.bind(*a, **k)
-                self.calls.append((__name, dict(bound.arguments)))
-                return __real(*a, **k)
-            setattr(ops, name, wrapper)
-        return self
-
-    def __exit__(self, *exc):
-        for name, real in self._saved.items():
-            setattr(ops, name, real)
-        return False
+def _pad8(b):
+    return b + b"\0" * (-len(b) % 8)
 
 
 def _storage_key(t):
@@ -59,104 +51,145 @@ def _storage_key(t):
 
 
 class _Encoder:
-    """tensor -> view handle; buffers are the storages some launch writes (plus the network input)."""
+    """tensor -> ref; buffers are the storages some launch writes (plus the network input), everything else is a constant."""
 
     def __init__(self, buffer_storages):
         self.buf_ids = {}            # storage ptr -> id
         self.buf_numel = []
-        self.const_ids = {}          # (ptr, shape, stride) -> id
-        self.consts = []
+        self.const_ids = {}          # (ptr, numel) -> id
+        self.consts = []             # contiguous float32 CPU tensors
         self.buffer_storages = buffer_storages
 
-    def view(self, t):
+    def ref(self, t):
+        if t is None:
+            return (REF_NULL, 0, 0, 0)
         assert t.dtype == torch.float32, "plan tensors are float32"
         key = _storage_key(t)
         if key in self.buffer_storages:
             if key not in self.buf_ids:
                 self.buf_ids[key] = len(self.buf_numel)
                 self.buf_numel.append(t.untyped_storage().nbytes() // 4)
-            off = (t.data_ptr() - key) // 4
-            return ("buf", self.buf_ids[key], int(off), tuple(t.shape), tuple(t.stride()))
-        ck = (t.data_ptr(), tuple(t.shape), tuple(t.stride()))
+            return (REF_BUF, self.buf_ids[key], (t.data_ptr() - key) // 4, t.numel())
+        assert t.is_contiguous(), "plan constants are contiguous"
+        ck = (t.data_ptr(), t.numel())
         if ck not in self.const_ids:
             self.const_ids[ck] = len(self.consts)
-            self.consts.append(t.detach().contiguous().cpu())
-        return ("const", self.const_ids[ck])
+            self.consts.append(t.detach().reshape(-1).cpu())
+        return (REF_CONST, self.const_ids[ck], 0, t.numel())
 
-    def value(self, v):
-        if isinstance(v, torch.Tensor):
-            return self.view(v)
-        if isinstance(v, (list, tuple)):
-            return [self.value(x) for x in v]
-        if v is None or isinstance(v, (bool, int, float, str)):
-            return v
-        raise TypeError("cannot serialise plan argument of type %s" % type(v).__name__)
+
+def _pack_ref(r):
+    return struct.pack("<IIQQ", *r)
+
+
+def serialize(launches, meta, inp, outputs, abi):
+    """launches: [(kind, name, flops, ops.Launch)] -> bytes of a plan file."""
+    written = {_storage_key(inp)} | {_storage_key(l.out) for _, _, _, l in launches}
+    enc = _Encoder(written)
+    in_ref = enc.ref(inp)
+    op_blobs = []
+    for _, _, _, l in launches:
+        desc = bytes(l.desc) if l.desc is not None else b""
+        refs = b"".join(_pack_ref(enc.ref(t)) for t in l.tensors)
+        ints = _pad8(struct.pack("<%di" % len(l.ints), *l.ints))
+        op_blobs.append(struct.pack("<IIIIII", ops.FN_IDS[l.fn], len(desc), len(l.tensors), len(l.ints), l.out_index, 0)
+                        + _pad8(desc) + refs + ints)
+    out_blob = b"".join(_pack_ref(enc.ref(o)) + struct.pack("<4I", *o.shape) for o in outputs)
+    mj = dict(meta)
+    mj["ops"] = [{"kind": k, "name": n, "flops": int(f)} for k, n, f, _ in launches]
+    mjs = json.dumps(mj).encode()
+    B, _, H, W = inp.shape
+    head = MAGIC + struct.pack("<IIIIIIIIII", abi, B, H, W, len(enc.buf_numel), len(enc.consts), len(launches), len(outputs), len(mjs), 0)
+    head += _pad8(mjs) + struct.pack("<%dQ" % len(enc.buf_numel), *enc.buf_numel)
+    body = _pack_ref(in_ref) + out_blob + b"".join(op_blobs)
+    table_len = 16 * len(enc.consts)
+    pos = len(head) + table_len + len(body)
+    table, data = b"", []
+    for c in enc.consts:
+        pos += -pos % 64
+        table += struct.pack("<QQ", c.numel(), pos)
+        data.append((pos, c))
+        pos += 4 * c.numel()
+    out = bytearray(head + table + body)
+    for off, c in data:
+        out += b"\0" * (off - len(out))
+        out += c.numpy().tobytes()
+    return bytes(out)
 
 
 def save_plan(engine, path):
-    """Record `engine`'s launch schedule (one eager run on its device) and write the plan file."""
-    dev = engine.device
-    per_launch = []
-    with torch.cuda.device(dev):
-        torch.cuda.synchronize(dev)
-        for kind, name, flops, fn in engine.launches:
-            with _Recorder() as rec:
-                fn()
-            if len(rec.calls) != 1:
-                raise RuntimeError("launch %s issued %d recorded calls (expected 1)" % (name, len(rec.calls)))
-            per_launch.append((kind, name, flops, rec.calls[0]))
-        torch.cuda.synchronize(dev)
-    written = {_storage_key(engine.input)}
-    for _, _, _, (_, args) in per_launch:
-        written.add(_storage_key(args[OUT_PARAM]))
-    enc = _Encoder(written)
-    plan_ops = []
-    for kind, name, flops, (fname, args) in per_launch:
-        plan_ops.append({"kind": kind, "name": name, "flops": int(flops), "fn": fname,
-                         "args": {k: enc.value(v) for k, v in args.items()}})
-    plan = {"format": FORMAT, "version": VERSION,
-            "meta": {"arch": engine.arch, "batch": engine.B, "height": engine.H, "width": engine.W,
-                     "flops_per_image": int(engine.flops_per_image), "abi": int(_lib.lib().cp_abi_version())},
-            "input": enc.view(engine.input), "outputs": [enc.view(o) for o in engine.outputs],
-            "buffers": enc.buf_numel, "consts": enc.consts, "ops": plan_ops}
-    torch.save(plan, path)
-    return plan
+    """Write `engine`'s compiled plan (packed constants + launch schedule) to `path`."""
+    meta = {"arch": engine.arch, "flops_per_image": int(engine.flops_per_image)}
+    blob = serialize(engine.launches, meta, engine.input, engine.outputs, int(_lib.lib().cp_abi_version()))
+    with open(path, "wb") as f:
+        f.write(blob)
+    return len(blob)
 
 
-class _Decoder:
-    def __init__(self, plan, device):
-        self.bufs = [torch.empty((n,), dtype=torch.float32, device=device) for n in plan["buffers"]]
-        self.consts = [c.to(device) for c in plan["consts"]]
+class _Reader:
+    def __init__(self, blob):
+        self.b, self.p = blob, 0
 
-    def view(self, h):
-        if h[0] == "buf":
-            _, bid, off, shape, stride = h
-            return torch.as_strided(self.bufs[bid], tuple(shape), tuple(stride), off)
-        return self.consts[h[1]]
-
-    def value(self, v):
-        if isinstance(v, tuple) and len(v) > 0 and v[0] in ("buf", "const"):      # views are tuples, argument lists are lists
-            return self.view(v)
-        if isinstance(v, list):
-            return [self.value(x) for x in v]
+    def take(self, fmt):
+        v = struct.unpack_from(fmt, self.b, self.p)
+        self.p += struct.calcsize(fmt)
         return v
 
+    def raw(self, n, pad=True):
+        v = bytes(self.b[self.p:self.p + n])
+        self.p += n + ((-n % 8) if pad else 0)
+        return v
 
-def check_plan(plan):
-    """Schema / version check of a loaded plan dict (host only)."""
-    if not isinstance(plan, dict) or plan.get("format") != FORMAT:
-        raise ValueError("not a centerpose_amd plan file")
-    if plan.get("version") != VERSION:
-        raise ValueError("plan version %r is not supported (this build reads version %d)" % (plan.get("version"), VERSION))
-    for key in ("meta", "input", "outputs", "buffers", "consts", "ops"):
-        if key not in plan:
-            raise ValueError("plan file is missing %r" % key)
-    for op in plan["ops"]:
-        if op["fn"] not in LAUNCH_FNS:
-            raise ValueError("plan op %r uses unknown launch function %r" % (op["name"], op["fn"]))
-        if OUT_PARAM not in op["args"]:
-            raise ValueError("plan op %r has no output" % op["name"])
-    return plan["meta"]
+    def ref(self):
+        return self.take("<IIQQ")
+
+
+def parse(blob):
+    """bytes -> dict(abi, B, H, W, meta, buffers, consts [(numel, offset)], input ref, outputs [(ref, shape)],
+    ops [(fn name, desc bytes, refs, ints, out_index)]).  Host only; validates structure, raises ValueError."""
+    if len(blob) < 48 or bytes(blob[:8]) != MAGIC:
+        raise ValueError("not a centerpose_amd plan file (magic %r)" % bytes(blob[:8]))
+    r = _Reader(blob)
+    r.p = 8
+    abi, B, H, W, nbuf, nconst, nops, nout, mlen, _ = r.take("<IIIIIIIIII")
+    try:
+        meta = json.loads(r.raw(mlen).decode())
+    except ValueError:
+        raise ValueError("plan file: corrupt meta block")
+    buffers = list(r.take("<%dQ" % nbuf))
+    consts = [r.take("<QQ") for _ in range(nconst)]
+    for n, off in consts:
+        if off % 4 or off + 4 * n > len(blob):
+            raise ValueError("plan file: constant outside the file")
+
+    def check_ref(ref):
+        kind, i, off, n = ref
+        if kind == REF_BUF and (i >= nbuf or off >= buffers[i]):
+            raise ValueError("plan file: buffer reference out of range")
+        if kind == REF_CONST and i >= nconst:
+            raise ValueError("plan file: constant reference out of range")
+        if kind not in (REF_NULL, REF_BUF, REF_CONST):
+            raise ValueError("plan file: bad reference kind %d" % kind)
+        return ref
+    inp = check_ref(r.ref())
+    outputs = [(check_ref(r.ref()), r.take("<4I")) for _ in range(nout)]
+    plan_ops = []
+    for _ in range(nops):
+        fn, dlen, nptr, nint, oi, _ = r.take("<IIIIII")
+        if fn not in FN_NAMES:
+            raise ValueError("plan file: unknown launch function id %d" % fn)
+        name = FN_NAMES[fn]
+        want = ctypes.sizeof(DESC_TYPES[name]) if name in DESC_TYPES else 0
+        if dlen != want or oi >= nptr:
+            raise ValueError("plan file: op %s has a %d-byte descriptor (this build expects %d)" % (name, dlen, want))
+        desc = r.raw(dlen)
+        refs = [check_ref(r.ref()) for _ in range(nptr)]
+        ints = list(r.take("<%di" % nint))
+        r.p += (-4 * nint) % 8
+        plan_ops.append((name, desc, refs, ints, oi))
+    if len(meta.get("ops", ())) != nops:
+        raise ValueError("plan file: meta lists %d ops, schedule has %d" % (len(meta.get("ops", ())), nops))
+    return dict(abi=abi, B=B, H=H, W=W, meta=meta, buffers=buffers, consts=consts, input=inp, outputs=outputs, ops=plan_ops)
 
 
 def load_plan(path, device="cuda", use_graph=True):
@@ -165,30 +198,33 @@ def load_plan(path, device="cuda", use_graph=True):
     if not torch.cuda.is_available():
         raise _lib.CenterposeHipError("load_plan needs a HIP device; there is no CPU fallback")
     L = _lib.lib()
-    plan = torch.load(path, map_location="cpu", weights_only=False)
-    meta = check_plan(plan)
-    if meta["abi"] != L.cp_abi_version():
-        raise ValueError("plan was written for ABI %d, library has %d" % (meta["abi"], L.cp_abi_version()))
+    blob = np.fromfile(path, dtype=np.uint8)
+    p = parse(memoryview(blob))
+    if p["abi"] != L.cp_abi_version():
+        raise ValueError("plan was written for ABI %d, library has %d" % (p["abi"], L.cp_abi_version()))
     dev = torch.device(device)
     with torch.cuda.device(dev):
-        dec = _Decoder(plan, dev)
-        launches = []
-        for op in plan["ops"]:
-            fn_ = getattr(ops, op["fn"])
-            kwargs = {k: dec.value(v) for k, v in op["args"].items()}
+        bufs = [torch.empty((n,), dtype=torch.float32, device=dev) for n in p["buffers"]]
+        consts = [torch.from_numpy(blob[off:off + 4 * n].view(np.float32).copy()).to(dev) for n, off in p["consts"]]
 
-            def fn(fn_=fn_, kwargs=kwargs):
-                fn_(**kwargs)
-            launches.append((op["kind"], op["name"], op["flops"], fn))
+        def view(ref):
+            kind, i, off, n = ref
+            if kind == REF_NULL:
+                return None
+            return bufs[i][off:off + n] if kind == REF_BUF else consts[i]
+        launches = []
+        for (name, desc, refs, ints, oi), m in zip(p["ops"], p["meta"]["ops"]):
+            d = DESC_TYPES[name].from_buffer_copy(desc) if name in DESC_TYPES else None
+            launches.append((m["kind"], m["name"], m["flops"], ops.Launch(name, d, [view(r) for r in refs], ints, oi)))
         eng = Engine.__new__(Engine)
-        eng.arch, eng.B, eng.H, eng.W = meta["arch"], meta["batch"], meta["height"], meta["width"]
+        eng.arch, eng.B, eng.H, eng.W = p["meta"]["arch"], p["B"], p["H"], p["W"]
         eng.device = dev
-        eng.input = dec.view(plan["input"])
+        eng.input = view(p["input"]).view(p["B"], 3, p["H"], p["W"])
         eng.input.zero_()
         eng.launches = launches
-        eng.outputs = [dec.view(h) for h in plan["outputs"]]
-        eng.flops_per_image = meta["flops_per_image"]
-        eng.activation_bytes = 4 * sum(plan["buffers"])
+        eng.outputs = [view(r).view(*shape) for r, shape in p["outputs"]]
+        eng.flops_per_image = p["meta"]["flops_per_image"]
+        eng.activation_bytes = 4 * sum(p["buffers"])
         eng.graph = None
         eng.use_graph = use_graph
     return eng

@@ -4,8 +4,9 @@
  * sizes, no torch types.  All pointers are DEVICE pointers unless stated; `stream` is a
  * hipStream_t (NULL = default stream).  Every function returns 0 on success, non-zero on error
  * (1 = bad argument, 2 = launch/runtime failure); cp_last_error() gives the message
- * (thread-local).  Nothing synchronises the host; nothing allocates device memory; kernels are
- * enqueued on `stream` only (so a caller may capture a sequence of calls into a hipGraph).
+ * (thread-local).  The kernel entry points never synchronise the host and never allocate device memory; kernels
+ * are enqueued on `stream` only (so a caller may capture a sequence of calls into a hipGraph).  The plan handle
+ * (cp_plan_*) is the one exception and says so.
  *
  * File:line citations are relative to the reference checkout (/root/reference).
  * Activation layout: NHWC float32, `ld` = floats between consecutive pixels (>= C).
@@ -113,13 +114,18 @@ int cp_fill_f32(float* p, float v, long long n, void* stream);
 int cp_flip_merge_f32(const float* in, float* out, int C, int H, int W, int mode, const int* perm, void* stream);
 
 /* ---- device pre-/post-processing ---------------------------------------------------
+ * The 8-bit pixel arithmetic is OpenCV's (opencv-python, unpinned, requirements.txt): resize.cpp / imgwarp.cpp fixed-point
+ * bilinear paths, restated in oracle/prepost_np.py; parity against cv2 itself is unpinned (cv2 is not installable here).
+ * cp_resize_u8: cv2.resize(image, (NW, NH)) with the default INTER_LINEAR (base_detector.py:47); DEVICE uint8 [H,W,3] ->
+ *   DEVICE uint8 [NH,NW,3].
  * cp_preprocess_u8_f32: cv2.warpAffine(INTER_LINEAR, border 0) + (x/255 - mean)/std + HWC->CHW of
- *   lib/detectors/base_detector.py:46-56.  img: DEVICE uint8 [H,W,3]; M: HOST float[6], the 2x3 matrix mapping
- *   an OUTPUT pixel to source coordinates (inverse of the matrix given to warpAffine); mean/std_: HOST float[3];
- *   out: DEVICE float32 NCHW [1 or 2,3,OH,OW]; flip != 0 also writes the mirrored twin as batch entry 1.
+ *   lib/detectors/base_detector.py:48-56.  img: DEVICE uint8 [H,W,3]; M: HOST double[6], the 2x3 matrix given to
+ *   warpAffine (source -> destination, `trans_input`); mean/std_: HOST float[3];
+ *   out: DEVICE float32 NCHW [1 or 2,3,OH,OW]; flip != 0 also writes the mirrored twin as batch entry 1 (:57-58).
  * cp_transform_dets_f32: lib/utils/post_process.py:8-19 + lib/utils/image.py:19-24 on the device: the 2 box corners
  *   and J keypoints of dets[B,K,5+3J] through the per-image 2x3 double matrix trans[B][6], then / scale. */
-int cp_preprocess_u8_f32(const unsigned char* img, int H, int W, const float* M, float* out, int OH, int OW, const float* mean,
+int cp_resize_u8(const unsigned char* src, int H, int W, unsigned char* dst, int NH, int NW, void* stream);
+int cp_preprocess_u8_f32(const unsigned char* img, int H, int W, const double* M, float* out, int OH, int OW, const float* mean,
                          const float* std_, int flip, void* stream);
 int cp_transform_dets_f32(const float* dets, float* out, const double* trans, int B, int K, int J, float scale, void* stream);
 
@@ -135,11 +141,37 @@ int cp_transform_dets_f32(const float* dets, float* out, const double* trans, in
  * ws_scores[B,1+J,K] float32 / ws_inds[B,1+J,K] int32 are caller-owned scratch that also
  * returns the top-K peaks: plane 0 = person centres, plane 1+j = joint j candidates
  * (flat index y*W+x; order = value desc, index asc).
- * Limits: K <= 256, cat*H*W <= 32768 (the plane's sort keys stay resident in LDS). */
+ * Limits: K <= 256 (the reference's TEST.TOPK is 100), K <= H*W.  Any map size: planes up to 32768 keys are
+ * LDS-resident in one piece, larger ones (FIX_RES = false inputs, TEST_SCALES > 1) stream through LDS in chunks. */
 int cp_decode_workspace_bytes(int B, int J, int K, size_t* scores_bytes, size_t* inds_bytes);
 int cp_multi_pose_decode_f32(const float* heat, const float* wh, const float* kps, const float* reg,
                              const float* hm_hp, const float* hp_offset, int B, int cat, int J, int H,
                              int W, int K, float* dets, float* ws_scores, int* ws_inds, void* stream);
+
+/* ---- plan handle: a whole network behind three calls -----------------------------
+ * Replaces BackBoneWithHead.forward (lib/models/model.py:57-59: head_model(backbone_model(x))) for one compiled
+ * (arch, B, H, W) and, with cp_plan_process, MultiPoseDetector.process (lib/detectors/multi_pose.py:29-60; flip test
+ * excluded) -- no Python involved.  A plan file / blob (layout: centerpose_amd/plan.py; written by Engine.save_plan) holds
+ * the packed, BN-folded, Winograd-transformed constants and the schedule of the launches above.
+ * cp_plan_load / cp_plan_create are the ONLY entry points of this library that allocate device memory (activation
+ * buffers, constants; owned by the handle, released by cp_plan_destroy) and they synchronise the device once.
+ * use_graph != 0: the first cp_plan_forward runs the schedule eagerly, captures it into a hipGraph, later calls replay it.
+ * cp_plan_forward: images = DEVICE float32 NCHW [B,3,H,W] (mean/std-normalised, base_detector.py:53-58) or NULL when the
+ *   caller wrote cp_plan_input() itself; enqueues on `stream`, no host synchronisation after the first call.
+ * cp_plan_output: device pointer + NCHW shape of head i of [hm, wh, hps, reg, hm_hp, hp_offset] (keypoint.py:40-42);
+ *   hm and hm_hp are already sigmoided (multi_pose.py:35-37 fused into the head epilogue).
+ * cp_plan_process: forward + cp_multi_pose_decode_f32 -> dets DEVICE float32 [B,K,5+3J]. */
+typedef struct cp_plan cp_plan;
+int cp_plan_load(const char* path, int use_graph, cp_plan** out);
+int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_plan** out);
+int cp_plan_info(const cp_plan* plan, int* B, int* H, int* W, int* n_outputs, int* n_launches);
+float* cp_plan_input(const cp_plan* plan);
+int cp_plan_output(const cp_plan* plan, int i, float** dev_ptr, int shape[4]);
+int cp_plan_forward(cp_plan* plan, const float* images, void* stream);
+int cp_plan_process(cp_plan* plan, const float* images, int K, float* dets, void* stream);
+int cp_plan_destroy(cp_plan* plan);
+/* stream-ordered device-to-device copy (for callers that keep a plan's outputs beyond the next forward) */
+int cp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 
 /* ---- host: soft-NMS of merged results --------------------------------------------------------
  * Replaces soft_nms_39 (lib/external/nms.pyx:172-275; called from multi_pose.py:76-77).

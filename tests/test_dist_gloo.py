@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, global_batch, q):
+def _worker(rank, world, port, batches, q):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
@@ -31,42 +31,58 @@ def _worker(rank, world, port, global_batch, q):
     from oracle import decode_np
     r, w, _ = cpd.init_from_env("gloo")
     assert (r, w) == (rank, world)
-    inp = cases.decode_random(42, B=global_batch, H=32, W=32)
-    lo, hi = cpd.shard_range(global_batch, rank, world)
-    local = decode_np.multi_pose_decode(inp["hm"][lo:hi], inp["wh"][lo:hi], inp["hps"][lo:hi], inp["reg"][lo:hi],
-                                        inp["hm_hp"][lo:hi], inp["hp_offset"][lo:hi], K=20)
-    full = cpd.gather_dets(torch.from_numpy(local))
+    out = []
+    gat = cpd.DetsGatherer()                 # sizes exchanged per call (global batch unknown to the gatherer)
+    for step, global_batch in enumerate(batches):
+        inp = cases.decode_random(42 + step, B=global_batch, H=32, W=32)
+        lo, hi = cpd.shard_range(global_batch, rank, world)
+        local = decode_np.multi_pose_decode(inp["hm"][lo:hi], inp["wh"][lo:hi], inp["hps"][lo:hi], inp["reg"][lo:hi],
+                                            inp["hm_hp"][lo:hi], inp["hp_offset"][lo:hi], K=20)
+        t = torch.from_numpy(local)
+        a = cpd.gather_dets(t)                                   # sizes exchanged
+        b = cpd.gather_dets(t, global_batch=global_batch)        # sizes from shard_range
+        gat.submit(t)
+        c = gat.collect()
+        assert torch.equal(a, b) and torch.equal(a, c)
+        out.append(a.numpy())
     dist.barrier()
-    q.put((rank, full.numpy()))
+    q.put((rank, out))
     dist.destroy_process_group()
 
 
-def _run(global_batch):
+def _run(batches):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import cases
     from oracle import decode_np
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, global_batch, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, batches, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=120) for _ in procs)
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    inp = cases.decode_random(42, B=global_batch, H=32, W=32)
-    ref = decode_np.multi_pose_decode(inp["hm"], inp["wh"], inp["hps"], inp["reg"], inp["hm_hp"], inp["hp_offset"], K=20)
-    for r in range(2):
-        assert res[r].shape == ref.shape and np.array_equal(res[r], ref)
+    for step, global_batch in enumerate(batches):
+        inp = cases.decode_random(42 + step, B=global_batch, H=32, W=32)
+        ref = decode_np.multi_pose_decode(inp["hm"], inp["wh"], inp["hps"], inp["reg"], inp["hm_hp"], inp["hp_offset"], K=20)
+        for r in range(2):
+            assert res[r][step].shape == ref.shape and np.array_equal(res[r][step], ref)
 
 
 def test_allgather_equal_shards():
-    _run(4)
+    _run([4])
 
 
 def test_allgather_ragged_shards():
-    _run(5)
+    _run([5])
+
+
+def test_allgather_shard_sizes_change_between_steps():
+    """A full global batch followed by a ragged last one (and back) inside ONE process group: shard sizes are never
+    cached across calls (a stale equal-size assumption would mis-size the collective and hang or corrupt)."""
+    _run([4, 5, 3, 4])
 
 
 def test_shard_range_covers_batch():

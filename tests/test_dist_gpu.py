@@ -1,0 +1,67 @@
+"""GPU: the N>1 path of bench.py as the driver launches it -- `python bench.py --gpus N` with NO launcher around it must
+spawn one rank per GPU itself (torch.distributed.run, 127.0.0.1 rendezvous), shard the global batch, gather the decoded
+poses and print one JSON line whose `ranks` is the world size the process group saw.
+
+* >= 2 visible devices: world_size 2 over nccl (RCCL), one GPU per rank.
+* 1 visible device (the gpurun box): the same control flow with both ranks on GPU 0 over gloo (CP_DIST_BACKEND=gloo):
+  RCCL cannot place two ranks on one device, the launcher / sharding / gather / timing code is identical.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(env_extra):
+    env = dict(os.environ, **env_extra)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "2",
+                        "--no-cpu-baseline", "--no-profile"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks():
+    multi = torch.cuda.device_count() >= 2
+    line = _bench({} if multi else {"CP_DIST_BACKEND": "gloo"})
+    assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == ("nccl" if multi else "gloo")
+    assert line["config"]["global_batch"] == 4 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["steps"] == 3 and abs(line["value"] - 4 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-3
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X for an RCCL world of 2")
+def test_gather_dets_over_rccl_matches_single_process(tmp_path):
+    """world_size 2 over nccl: every rank's gathered detections equal the single-process decode of the global batch."""
+    code = r"""
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import cases
+from centerpose_amd import dist as cpd
+from centerpose_amd.decode import multi_pose_decode
+rank, world, local = cpd.init_from_env("nccl")
+torch.cuda.set_device(local)
+inp = {k: torch.from_numpy(v).cuda() for k, v in cases.decode_random(5, B=5).items()}
+full = multi_pose_decode(inp["hm"], inp["wh"], inp["hps"], inp["reg"], inp["hm_hp"], inp["hp_offset"], K=100)
+lo, hi = cpd.shard_range(5, rank, world)
+mine = multi_pose_decode(*(inp[k][lo:hi] for k in ("hm", "wh", "hps", "reg", "hm_hp", "hp_offset")), K=100)
+g = cpd.DetsGatherer(global_batch=5)
+g.submit(mine)
+got = g.collect()
+torch.cuda.synchronize()
+assert torch.equal(got, full), "rank %d" % rank
+dist.barrier(); dist.destroy_process_group()
+"""
+    script = tmp_path / "rccl_gather.py"
+    script.write_text(code)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29517", str(script), ROOT], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

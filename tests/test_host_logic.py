@@ -141,32 +141,43 @@ def test_flip_helpers_roundtrip():
     assert np.array_equal(decode_np.flip_lr_off(decode_np.flip_lr_off(hps)), hps)
 
 
-def test_plan_format_encode_decode_and_schema(tmp_path):
-    """Plan file helpers on CPU tensors: buffer views (offset / stride) and constants survive encode -> torch.save ->
-    decode; schema errors are reported."""
-    from centerpose_amd import plan
-    buf = torch.arange(4 * 6 * 8, dtype=torch.float32).reshape(4, 6, 8)
-    view = buf[1:3, :, 2:6]                                  # strided view into a written storage
-    const = torch.randn(5, 7)
-    enc = plan._Encoder({buf.untyped_storage().data_ptr()})
-    args = {"srcs": [view, buf], "wp": const, "out": buf, "pad_yx": (1, 0), "res": None, "relu": True}
-    enc_args = {k: enc.value(v) for k, v in args.items()}
-    assert enc_args["srcs"][0][:3] == ("buf", 0, 8 * 6 + 2) and enc_args["wp"] == ("const", 0) and enc_args["pad_yx"] == [1, 0]
-    p = {"format": plan.FORMAT, "version": plan.VERSION, "meta": {"arch": "x", "abi": 1}, "input": enc.view(buf), "outputs": [],
-         "buffers": enc.buf_numel, "consts": enc.consts, "ops": [{"kind": "conv", "name": "n", "flops": 1, "fn": "conv2d", "args": enc_args}]}
-    f = str(tmp_path / "p.pt")
-    torch.save(p, f)
-    q = torch.load(f, weights_only=False)
-    assert plan.check_plan(q) == {"arch": "x", "abi": 1}
-    dec = plan._Decoder(q, "cpu")
-    dec.bufs[0].copy_(buf.reshape(-1))
-    got = {k: dec.value(v) for k, v in q["ops"][0]["args"].items()}
-    assert torch.equal(got["srcs"][0], view) and got["srcs"][0].stride() == view.stride()
-    assert torch.equal(got["wp"], const) and got["pad_yx"] == [1, 0] and got["res"] is None and got["relu"] is True
+def test_plan_format_serialize_parse_and_schema():
+    """Binary plan format on CPU tensors (no pickle): buffer views (offsets), constants, descriptor bytes and integer
+    arguments survive serialize -> parse; corrupt files are rejected."""
+    import struct
+    from centerpose_amd import ops, plan
+    inp = torch.zeros(2, 3, 8, 8)
+    store = torch.zeros(2 * 8 * 8 * 16 + 64)
+    act = store[64:].view(2, 8, 8, 16)                         # view with an offset into a written storage
+    w, sc, sh = torch.randn(16, 48), torch.ones(16), torch.zeros(16)
+    out = torch.zeros(2, 1, 8, 8)
+    l1 = ops.conv2d_launch([inp], w, sc, sh, act, kh=4, kw=4, stride=1, pad=0, cout=16, in_nchw=True, Ho=8, Wo=8)
+    l2 = ops.maxpool2d_launch(act, act, 1, 1, 0)
+    wp = torch.randn(16, 16)
+    l3 = ops.conv2d_launch([act], wp, sc, sh, out, kh=1, kw=1, cout=1, out_nchw=True, act=ops.ACT_SIGMOID)
+    blob = plan.serialize([("conv", "a", 10, l1), ("pool", "p", 0, l2), ("conv", "h", 5, l3)],
+                          {"arch": "x", "flops_per_image": 3}, inp, [out], 2)
+    p = plan.parse(memoryview(blob))
+    assert (p["abi"], p["B"], p["H"], p["W"]) == (2, 2, 8, 8) and p["meta"]["arch"] == "x"
+    assert p["buffers"] == [inp.numel(), store.numel(), out.numel()]
+    assert [o[0] for o in p["ops"]] == ["cp_conv2d_f32", "cp_maxpool2d_nhwc_f32", "cp_conv2d_f32"]
+    assert p["ops"][1][3] == l2.ints and p["ops"][0][1] == bytes(l1.desc)
+    assert p["ops"][0][2][-1] == (plan.REF_BUF, 1, 64, act.numel())          # out of l1: buffer 1, offset 64 floats
+    assert p["ops"][0][2][1] == (plan.REF_NULL, 0, 0, 0)                      # unused source slot
+    kinds = [r[0] for r in p["ops"][2][2]]
+    assert kinds[4] == plan.REF_CONST and p["outputs"] == [((plan.REF_BUF, 2, 0, out.numel()), (2, 1, 8, 8))]
+    # constants come back bit-identical, scale / shift are stored once (shared by both convs)
+    n, off = p["consts"][p["ops"][2][2][4][1]]
+    assert np.array_equal(np.frombuffer(blob, np.float32, n, off), wp.numpy().reshape(-1))
+    assert len(p["consts"]) == 4
+    d = ops.ConvDesc.from_buffer_copy(p["ops"][2][1])
+    assert (d.kh, d.Cout, d.outNCHW, d.act) == (1, 1, 1, ops.ACT_SIGMOID)
     with pytest.raises(ValueError):
-        plan.check_plan({"format": "other"})
-    with pytest.raises(ValueError):
-        plan.check_plan(dict(q, version=99))
-    bad = dict(q, ops=[dict(q["ops"][0], fn="not_a_launch")])
-    with pytest.raises(ValueError):
-        plan.check_plan(bad)
+        plan.parse(memoryview(b"NOTAPLAN" + blob[8:]))
+    with pytest.raises(ValueError):                             # unknown launch function id
+        bad = bytearray(blob)
+        pos = blob.index(struct.pack("<IIII", ops.FN_IDS["cp_maxpool2d_nhwc_f32"], 0, 2, 9))
+        bad[pos:pos + 4] = struct.pack("<I", 99)
+        plan.parse(memoryview(bytes(bad)))
+    with pytest.raises((ValueError, struct.error)):             # truncated
+        plan.parse(memoryview(blob[:200]))

@@ -1,25 +1,24 @@
 """HBM traffic per launch per kernel from rocprofv3 PMC passes (GPU box).
 usage: pmc_traffic.py out.json [bench args...]
 Two separate passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE), each with --kernel-trace only, on
-`bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline`.  Counter unit is KB; FETCH_SIZE is doubled per
-MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B).  Writes the per-kernel table and the launch-weighted
-average over the GEMM-family kernels (conv / winograd / dcn) that bench.py reports as roofline.traffic."""
+`bench.py --steps 2 --warmup 1 --no-graph --no-cpu-baseline --no-profile`.  Counter unit is KB; FETCH_SIZE is doubled per
+MI355X_MICROARCH.md (gfx950 tallies 128-B requests as 64 B).  Writes the per-kernel table and, per kernel family (keyed
+by the C entry point that launches it), the launch-weighted average bench.py reports as roofline.traffic for the
+dominant kernel."""
 import csv, glob, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PER_STEP = None
-GEMM = ("conv3x3_wino", "igemm_conv_kernel", "dcn_igemm_kernel", "conv3x3_patch_kernel", "stem7x7_kernel")
+FAMILY = (("dcn_igemm_kernel", "cp_dcn_v2_f32"), ("conv3x3_wino", "cp_conv3x3_winograd_f32"), ("igemm_conv_kernel", "cp_conv2d_f32"),
+          ("conv3x3_patch_kernel", "cp_conv2d_f32"), ("stem7x7_kernel", "cp_stem7x7_f32"), ("head_fused", "cp_head_fused_f32"),
+          ("maxpool_nhwc_kernel", "cp_maxpool2d_nhwc_f32"), ("dw_deconv_add_kernel", "cp_dw_deconv_add_nhwc_f32"),
+          ("sum_up_kernel", "cp_sum_up_nhwc_f32"), ("nms_topk_kernel", "decode"), ("pose_assign_kernel", "decode"))
 
 
 def one_pass(counter, args):
     d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", "pmc_" + counter)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline"] + args
-    r_ = subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=False, text=True)
-    global PER_STEP
-    for line in r_.stdout.splitlines():
-        if line.startswith("{") and "roofline" in line:
-            PER_STEP = json.loads(line)["roofline"]["launches_per_step"]
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--no-profile"] + args
+    subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=False, text=True)
     acc = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -34,20 +33,25 @@ def one_pass(counter, args):
 def main():
     out, args = sys.argv[1], sys.argv[2:]
     fetch, write = one_pass("FETCH_SIZE", args), one_pass("WRITE_SIZE", args)
-    kernels, tot, launches, per_step = {}, 0.0, 0, 0
+    kernels, fam = {}, {}
     for k in sorted(fetch, key=lambda k: -fetch[k][0]):
         fs, n = fetch[k]
         ws, _ = write.get(k, (0.0, n))
         kernels[k] = {"launches": n, "fetch_bytes_per_launch_corrected": int(2 * 1024 * fs / n), "write_bytes_per_launch": int(1024 * ws / n)}
-        if k.startswith(GEMM):
-            tot += 2 * 1024 * fs + 1024 * ws
-            launches += n
+        for prefix, f in FAMILY:
+            if k.startswith(prefix):
+                e = fam.setdefault(f, {"launches": 0, "fetch": 0.0, "write": 0.0})
+                e["launches"] += n
+                e["fetch"] += 2 * 1024 * fs
+                e["write"] += 1024 * ws
+                break
+    families = {f: {"launches_profiled": e["launches"], "fetch_bytes_per_launch_corrected": int(e["fetch"] / e["launches"]),
+                    "write_bytes_per_launch": int(e["write"] / e["launches"]),
+                    "traffic_bytes_per_launch_avg": int((e["fetch"] + e["write"]) / e["launches"])} for f, e in fam.items()}
     res = {"note": __doc__.split("usage")[0].strip() + " Passes: --pmc FETCH_SIZE / --pmc WRITE_SIZE, FETCH_SIZE doubled (gfx950).",
-           "bench_args": args, "kernels": kernels, "gemm_launches_profiled": launches,
-           "gemm_launches_per_step": PER_STEP,
-           "traffic_bytes_per_launch_avg": int(tot / max(launches, 1))}
+           "bench_args": args, "kernels": kernels, "families": families}
     json.dump(res, open(out, "w"), indent=1)
-    print("wrote", out, "gemm launches", launches, "avg bytes/launch", res["traffic_bytes_per_launch_avg"])
+    print("wrote", out, {f: v["traffic_bytes_per_launch_avg"] for f, v in families.items()})
 
 
 if __name__ == "__main__":
