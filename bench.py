@@ -32,13 +32,8 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-# C entry point -> device kernel family (names as rocprofv3 --kernel-trace prints them)
-KERNEL_OF = {"cp_dcn_v2_f32": "dcn_igemm_kernel", "cp_conv3x3_winograd_f32": "conv3x3_wino_kernel / conv3x3_wino_vs64_kernel",
-             "cp_conv2d_f32": "igemm_conv_kernel / conv3x3_patch_kernel", "cp_stem7x7_f32": "stem7x7_kernel",
-             "cp_head_fused_f32": "head_fused_kernel",
-             "cp_maxpool2d_nhwc_f32": "maxpool_nhwc_kernel", "cp_dw_deconv_add_nhwc_f32": "dw_deconv_add_kernel",
-             "cp_sum_up_nhwc_f32": "sum_up_kernel"}
-MFMA_FNS = ("cp_dcn_v2_f32", "cp_conv3x3_winograd_f32", "cp_conv2d_f32", "cp_stem7x7_f32", "cp_head_fused_f32")
+MFMA_KERNELS = ("dcn_igemm_kernel", "dcn_rega_kernel", "conv3x3_wino", "igemm_conv_kernel", "conv3x3_patch_kernel", "stem7x7_kernel",
+                "head_fused")
 
 
 def parse_args():
@@ -113,11 +108,12 @@ def cpu_baseline(arch):
 
 
 def roofline(eng, arch, B):
-    """Per-family accounting of one step from in-sequence HIP-event timings (Engine.profile_in_sequence)."""
+    """Per-kernel accounting of one step from in-sequence HIP-event timings (Engine.profile_in_sequence); kernels are the
+    template instantiations the launchers dispatched to (cp_last_kernel), named as rocprofv3 --kernel-trace prints them."""
     recs = eng.profile_in_sequence(iters=10)
     fam = {}
     for r in recs:
-        f = fam.setdefault(r["fn"], {"ms": 0.0, "flops": 0.0, "exe_flops": 0.0, "bytes": 0, "launches": 0})
+        f = fam.setdefault(r["kernel"] or r["fn"], {"ms": 0.0, "flops": 0.0, "exe_flops": 0.0, "bytes": 0, "launches": 0})
         f["ms"] += r["ms"]
         f["flops"] += r["flops"]
         f["exe_flops"] += r["flops"] * (16.0 / 36.0 if r["kind"] == "wino" else 1.0)    # F(2x2,3x3): 16 of 36 multiplies
@@ -126,11 +122,11 @@ def roofline(eng, arch, B):
     all_ms = sum(f["ms"] for f in fam.values())
     dom = max(fam, key=lambda k: fam[k]["ms"])
     d = fam[dom]
-    mm = [fam[k] for k in fam if k in MFMA_FNS]
+    mm = [fam[k] for k in fam if k.startswith(MFMA_KERNELS)]
     mm_ms = sum(f["ms"] for f in mm)
     tf = lambda flops, ms: flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     exe = tf(d["exe_flops"], d["ms"])
-    roof = {"bound": "mfma", "kernel": KERNEL_OF.get(dom, dom), "achieved": round(exe, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(exe, 2), "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(exe / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
             "definition": "achieved = MFMA FLOPs executed by the dominant kernel (largest share of the step's GPU time) / its "
                           "time, HIP events between consecutive launches of the step; Winograd launches count 16/36 of their "
@@ -138,12 +134,11 @@ def roofline(eng, arch, B):
             "algorithmic_tflops": round(tf(d["flops"], d["ms"]), 2),
             "time_share": round(d["ms"] / all_ms, 4), "launches": d["launches"],
             "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 1),
-            "families": {KERNEL_OF.get(k, k): {"ms_per_step": round(f["ms"], 3), "share": round(f["ms"] / all_ms, 4),
-                                               "launches": f["launches"],
-                                               "algorithmic_tflops": round(tf(f["flops"], f["ms"]), 1),
-                                               "executed_tflops": round(tf(f["exe_flops"], f["ms"]), 1),
-                                               "compulsory_tbps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e12, 2)}
-                         for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+            "kernels": {k: {"ms_per_step": round(f["ms"], 3), "share": round(f["ms"] / all_ms, 4), "launches": f["launches"],
+                            "algorithmic_tflops": round(tf(f["flops"], f["ms"]), 1),
+                            "executed_tflops": round(tf(f["exe_flops"], f["ms"]), 1),
+                            "compulsory_tbps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e12, 2)}
+                        for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
             "all_mfma_kernels": {"ms_per_step": round(mm_ms, 3),
                                  "algorithmic_tflops": round(tf(sum(f["flops"] for f in mm), mm_ms), 2),
                                  "executed_tflops": round(tf(sum(f["exe_flops"] for f in mm), mm_ms), 2),
@@ -155,9 +150,9 @@ def roofline(eng, arch, B):
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
         if arch == "dla_34" and B == 16:
-            k = pmc["families"].get(dom)
+            k = pmc["kernels"].get(dom)
             if k:
-                roof["traffic"] = k["traffic_bytes_per_launch_avg"]
+                roof["traffic"] = k["fetch_bytes_per_launch_corrected"] + k["write_bytes_per_launch"]
                 roof["traffic_unit"] = "bytes per launch (avg)"
                 roof["traffic_source"] = "profiles/r2_pmc_traffic.json (rocprofv3 --pmc, collected offline with this command)"
     except (OSError, KeyError, ValueError):

@@ -30,6 +30,7 @@ def lib():
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.cp_last_error.restype = ctypes.c_char_p
         _lib.cp_target_arch.restype = ctypes.c_char_p
+        _lib.cp_last_kernel.restype = ctypes.c_char_p
     return _lib
 
 

@@ -14,5 +14,17 @@ void cp_set_error(const char* fmt, ...)
 }
 
 extern "C" const char* cp_last_error(void) { return g_err; }
+
+// name of the device kernel the calling thread launched last (as rocprofv3 --kernel-trace prints it): lets a host-side
+// profiler attribute an entry point's time to the template instantiation the dispatch heuristics picked
+static thread_local char g_kernel[160] = "";
+void cp_note_kernel(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_kernel, sizeof(g_kernel), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* cp_last_kernel(void) { return g_kernel; }
 extern "C" int cp_abi_version(void) { return 2; }      // 2: plan handle (cp_plan_*), decode of any map size
 extern "C" const char* cp_target_arch(void) { return "gfx950"; }

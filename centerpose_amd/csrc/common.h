@@ -8,6 +8,7 @@
 // error plumbing for the C ABI (thread-local last error string)
 extern "C" const char* cp_last_error(void);
 void cp_set_error(const char* fmt, ...);
+void cp_note_kernel(const char* fmt, ...);      // cp_last_kernel(): the kernel instantiation a launcher dispatched to
 
 #define CP_CHECK_ARG(cond, ...)              \
     do {                                     \

@@ -247,6 +247,7 @@ static int launch_patch(const ConvArgs& a, hipStream_t s)
     const int tilesX = cp_cdiv(a.W, P3_TW), tilesY = cp_cdiv(a.H, P3_TH);
     const long long grid = (long long)a.B * tilesX * tilesY * (a.ldw / BN);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, tilesX, tilesY);
+    cp_note_kernel("conv3x3_patch_kernel<%d, %d, %d, %d>", BN, WAVES_M, WAVES_N, MF);
     return 0;
 }
 

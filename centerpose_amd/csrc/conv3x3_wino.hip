@@ -504,6 +504,7 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
     const long long dmax = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
     if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd: grid %lld too large", grid); return 1; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
+    cp_note_kernel("conv3x3_wino_kernel<%d, %d, %d, %d>", MT, NT, KS, NB);
     return 0;
 }
 
@@ -528,6 +529,7 @@ static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups)
     const long long dmax = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
     if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd: grid %lld too large", grid); return 1; }
     hipLaunchKernelGGL(conv3x3_wino_vs64_kernel, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd, NL);
+    cp_note_kernel("conv3x3_wino_vs64_kernel");
     return 0;
 }
 

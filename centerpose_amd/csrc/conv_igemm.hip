@@ -207,6 +207,7 @@ static int launch_conv(const ConvArgs& a, hipStream_t s)
     }
     const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN) * (a.nsub > 1 ? a.nsub : 1);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
+    cp_note_kernel("igemm_conv_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, WAVES_M, WAVES_N, MF, STEM ? "true" : "false");
     return 0;
 }
 

@@ -14,6 +14,7 @@
 // Per block: the (pixel, tap) sampling records {clamped corner base, dx, dy bits, 4 weights*mask}
 // are computed once into LDS (9 * BM * 20 B); each k-step then issues 4 corner float4 loads per
 // (pixel, 4-channel quad), blends in registers and stages the result k-major like a plain conv.
+#include <cstdlib>
 #include "igemm.h"
 
 #define DCN_MAX_TAPS 9
@@ -23,7 +24,12 @@ typedef float dcn_v2 __attribute__((ext_vector_type(2)));
 // cache line (8 lanes x 16 B) instead of a 64-byte half: PMC shows 71 % of the gather's line accesses miss the 32 KB L1
 // and go to L2 (5 blocks per CU thrash it), and L2 -> L1 moves 128-byte lines, so half-line gathers waste half of the
 // fabric bandwidth this kernel is bound by (tools/micro/l1_gather.hip: 19 vs 32 TB/s useful for 64 B vs 128 B segments).
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, int KW>
+// PF = 2: the gathers (and the weight slice) of k-step s+2 are issued during k-step s, i.e. they have a whole k-step of
+// MFMAs more to land before they are blended into LDS (PF = 1: half a k-step, 4 MFMAs = 256 cycles, less than an L2 hit
+// under load: PMC showed the waves parked on s_waitcnt / the barrier 28 % of the time).  Two register sets, loop unrolled
+// by two; no VMEM instruction sits inside a conditional (the waitcnt pass merges counters pessimistically at a join and would
+// wait for the loads it has just issued): the prefetch past the end re-reads the last k-step.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, int KW, int PF>
 __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs a)
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
@@ -49,42 +55,51 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     const int C = a.srcC[0], ld = a.srcLd[0];
     const float* __restrict__ x = a.src[0];
 
-    // ---- sampling records for every (tap, pixel) of this tile
-    for (int idx = tid; idx < ntap * BM; idx += IG_THREADS) {
-        const int t = idx / BM, pl = idx - t * BM;
-        const int m = m0 + pl;
-        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        int code = 0;
-        if (m < a.M) {
-            const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
-            const float* omp = a.om + (size_t)m * a.omLd;
-            const int ky = t / a.kw, kx = t - ky * a.kw;
-            const float offh = omp[2 * t], offw = omp[2 * t + 1];
-            float mk = omp[a.omMaskOff + t];
-            if (a.omSigmoid) mk = 1.0f / (1.0f + __expf(-mk));
-            const float h_im = (float)(oy * a.sy - a.py + ky * a.dily) + offh;
-            const float w_im = (float)(ox * a.sx - a.px + kx * a.dilx) + offw;
-            if (h_im > -1.f && w_im > -1.f && h_im < (float)a.H && w_im < (float)a.W) {
-                const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-                const int h_high = h_low + 1, w_high = w_low + 1;
-                const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-                const float hh = 1.f - lh, hw = 1.f - lw;
-                const bool t_ok = h_low >= 0, b_ok = h_high <= a.H - 1, l_ok = w_low >= 0, r_ok = w_high <= a.W - 1;
-                w4.x = (t_ok && l_ok) ? hh * hw * mk : 0.f;
-                w4.y = (t_ok && r_ok) ? hh * lw * mk : 0.f;
-                w4.z = (b_ok && l_ok) ? lh * hw * mk : 0.f;
-                w4.w = (b_ok && r_ok) ? lh * lw * mk : 0.f;
-                const int yl = t_ok ? h_low : 0, xl = l_ok ? w_low : 0;     // clamped, always in range
-                const int dy = (t_ok && b_ok) ? 1 : 0, dx = (l_ok && r_ok) ? 1 : 0;
-                code = (b * a.H * a.W + yl * a.W + xl) | (dx << 29) | (dy << 30);
-                // when the top/left corner is out of range the record's base already IS the
-                // bottom/right corner; its weight must then come from the matching slot:
-                if (!t_ok) { w4.x = w4.z; w4.y = w4.w; w4.z = 0.f; w4.w = 0.f; }
-                if (!l_ok) { w4.x = w4.y; w4.z = w4.w; w4.y = 0.f; w4.w = 0.f; }
+    // ---- sampling records for every (tap, pixel) of this tile.  A thread keeps ONE pixel (tid % BM) and walks the taps
+    // tid / BM, + 256 / BM, ...: the pixel's (b, oy, ox) decomposition (two integer divisions by run-time values, ~70 VALU) is
+    // done once instead of once per record, and the tap index is wave-uniform (scalar ky / kx).  Before this the prologue
+    // issued as many VALU instructions as the whole main loop of a 64-channel layer (PMC: 5 VALU per MFMA), and every
+    // VALU instruction costs matrix-pipe time.
+    {
+        static_assert(IG_THREADS % BM == 0, "one pixel per thread");
+        const int pl = tid % BM, m = m0 + pl;
+        const bool live = m < a.M;
+        const int b = live ? m / HoWo : 0, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
+        const float* omp = a.om + (size_t)(live ? m : 0) * a.omLd;
+        const int by = oy * a.sy - a.py, bx = ox * a.sx - a.px, bpix = b * a.H * a.W;
+        const float fH = (float)a.H, fW = (float)a.W;
+        for (int t = tid / BM; t < ntap; t += IG_THREADS / BM) {
+            const int ky = t / a.kw, kx = t - ky * a.kw;                   // wave-uniform
+            float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            int code = 0;
+            if (live) {
+                const float offh = omp[2 * t], offw = omp[2 * t + 1];
+                float mk = omp[a.omMaskOff + t];
+                if (a.omSigmoid) mk = 1.0f / (1.0f + __expf(-mk));
+                const float h_im = (float)(by + ky * a.dily) + offh;
+                const float w_im = (float)(bx + kx * a.dilx) + offw;
+                if (h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW) {
+                    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+                    const int h_high = h_low + 1, w_high = w_low + 1;
+                    const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
+                    const float hh = 1.f - lh, hw = 1.f - lw;
+                    const bool t_ok = h_low >= 0, b_ok = h_high <= a.H - 1, l_ok = w_low >= 0, r_ok = w_high <= a.W - 1;
+                    w4.x = (t_ok && l_ok) ? hh * hw * mk : 0.f;
+                    w4.y = (t_ok && r_ok) ? hh * lw * mk : 0.f;
+                    w4.z = (b_ok && l_ok) ? lh * hw * mk : 0.f;
+                    w4.w = (b_ok && r_ok) ? lh * lw * mk : 0.f;
+                    const int yl = t_ok ? h_low : 0, xl = l_ok ? w_low : 0;     // clamped, always in range
+                    const int dy = (t_ok && b_ok) ? 1 : 0, dx = (l_ok && r_ok) ? 1 : 0;
+                    code = (bpix + yl * a.W + xl) | (dx << 29) | (dy << 30);
+                    // when the top/left corner is out of range the record's base already IS the
+                    // bottom/right corner; its weight must then come from the matching slot:
+                    if (!t_ok) { w4.x = w4.z; w4.y = w4.w; w4.z = 0.f; w4.w = 0.f; }
+                    if (!l_ok) { w4.x = w4.y; w4.z = w4.w; w4.y = 0.f; w4.w = 0.f; }
+                }
             }
+            s_w[t * BM + pl] = w4;
+            s_code[t * BM + pl] = code;
         }
-        s_w[idx] = w4;
-        s_code[idx] = code;
     }
 
     typename IgAcc<MF>::type acc[T::TM][T::TN];
@@ -156,44 +171,110 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
 #pragma unroll
         for (int w = 0; w < KW; ++w) ig_store_b<T>(Bs + w * T::B_FLOATS, tid, br[w]);
     };
-    load_a(); advance();
-    load_b(0);
-    store_a(As0);
-    store_b(Bs0);
-    __syncthreads();
-    int cur = 0;
-    for (int ks = 0; ks < nk; ++ks) {
-        const bool more = ks + 1 < nk;
-        const float* Ac = As0 + cur * KW * T::A_FLOATS;
-        const float* Bc = Bs0 + cur * KW * T::B_FLOATS;
-        auto prefetch = [&]() __attribute__((always_inline)) { if (more) { load_a(); advance(); load_b(ks + 1); } };
-        // the next step's gathers are issued from inside the MFMA block (between the two k-steps, or half-way through one)
-        if constexpr (KW == 1) ig_compute<T, MF>(Ac, Bc, wm0, wn0, lane, acc, prefetch);
-        else {
-            ig_compute<T, MF>(Ac, Bc, wm0, wn0, lane, acc);
+    if constexpr (PF == 2) {
+        static_assert(KW == 1, "two-deep prefetch is built for 16-channel k-steps");
+        float4 C0[2][ASL], C1[2][ASL], C2[2][ASL], C3[2][ASL], W[2][ASL], BR[2][T::B_SLOTS];
+        int ltap = 0, lcl = 0;                                   // position of the next k-step to gather (saturates at the end)
+        auto gather = [&](int set, int ksb) __attribute__((always_inline)) {
+            if (lcl == 0) {                                      // LDS + VALU only
+#pragma unroll
+                for (int s2 = 0; s2 < ASL; ++s2) {
+                    const int pl = tid / QL + s2 * PPP;
+                    const int code = s_code[ltap * BM + pl];
+                    wq[s2] = s_w[ltap * BM + pl];
+                    o00[s2] = (unsigned)(code & 0x1FFFFFFF) * pixb + (unsigned)q * 16u;
+                    o01[s2] = o00[s2] + (((unsigned)code >> 29) & 1u) * pixb;
+                    o10[s2] = o00[s2] + (((unsigned)code >> 30) & 1u) * rowb;
+                    o11[s2] = o10[s2] + (o01[s2] - o00[s2]);
+                }
+            }
+            const char* xs = reinterpret_cast<const char*>(x) + (size_t)lcl * 4;      // uniform
+#pragma unroll
+            for (int s2 = 0; s2 < ASL; ++s2) {
+                C0[set][s2] = ig_ldg4(reinterpret_cast<const float*>(xs + o00[s2]));
+                C1[set][s2] = ig_ldg4(reinterpret_cast<const float*>(xs + o01[s2]));
+                C2[set][s2] = ig_ldg4(reinterpret_cast<const float*>(xs + o10[s2]));
+                C3[set][s2] = ig_ldg4(reinterpret_cast<const float*>(xs + o11[s2]));
+                W[set][s2] = wq[s2];
+            }
+            ig_load_b<T>(a, (ksb < nk ? ksb : nk - 1) * IG_BK, n0, tid, BR[set]);
+            if (ltap * C + lcl + IG_BK < a.K) { lcl += IG_BK; if (lcl >= C) { lcl = 0; ++ltap; } }
+        };
+        auto blend_store = [&](int set, float* As, float* Bs) __attribute__((always_inline)) {
+#pragma unroll
+            for (int s2 = 0; s2 < ASL; ++s2) {
+                const int pl = tid / QL + s2 * PPP;
+                const float4 w = W[set][s2];
+                const dcn_v2 wx = {w.x, w.x}, wy = {w.y, w.y}, wz = {w.z, w.z}, ww = {w.w, w.w};
+                const dcn_v2 lo = __builtin_elementwise_fma(ww, (dcn_v2){C3[set][s2].x, C3[set][s2].y},
+                                  __builtin_elementwise_fma(wz, (dcn_v2){C2[set][s2].x, C2[set][s2].y},
+                                  __builtin_elementwise_fma(wy, (dcn_v2){C1[set][s2].x, C1[set][s2].y}, wx * (dcn_v2){C0[set][s2].x, C0[set][s2].y})));
+                const dcn_v2 hi = __builtin_elementwise_fma(ww, (dcn_v2){C3[set][s2].z, C3[set][s2].w},
+                                  __builtin_elementwise_fma(wz, (dcn_v2){C2[set][s2].z, C2[set][s2].w},
+                                  __builtin_elementwise_fma(wy, (dcn_v2){C1[set][s2].z, C1[set][s2].w}, wx * (dcn_v2){C0[set][s2].z, C0[set][s2].w})));
+                *reinterpret_cast<float4*>(As + pl * IG_LDK + (q & 3) * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+            ig_store_b<T>(Bs, tid, BR[set]);
+        };
+        // one k-step: MFMAs on buffer `cur`, gathers of k-step ks+2 into register set `lset` from inside the MFMA block,
+        // then k-step ks+1 (register set lset^1, loaded one iteration ago) is blended into the other buffer
+        auto iter = [&](int ks, int cur, int lset) __attribute__((always_inline)) {
+            ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc,
+                              [&]() __attribute__((always_inline)) { gather(lset, ks + 2); });
             __builtin_amdgcn_sched_barrier(0);
-            prefetch();
-            __builtin_amdgcn_sched_barrier(0);
-            ig_compute<T, MF>(Ac + T::A_FLOATS, Bc + T::B_FLOATS, wm0, wn0, lane, acc);
-        }
-        // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
-        // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) {
-            store_a(As0 + (cur ^ 1) * KW * T::A_FLOATS);
-            store_b(Bs0 + (cur ^ 1) * KW * T::B_FLOATS);
-        }
+            blend_store(lset ^ 1, As0 + (cur ^ 1) * T::A_FLOATS, Bs0 + (cur ^ 1) * T::B_FLOATS);
+            __syncthreads();
+        };
+        gather(0, 0);
+        gather(1, 1);
+        blend_store(0, As0, Bs0);
         __syncthreads();
-        cur ^= 1;
+#pragma unroll 1
+        for (int ks = 0; ks < nk; ks += 2) {
+            iter(ks, 0, 0);
+            if (ks + 1 < nk) iter(ks + 1, 1, 1);
+        }
+    } else {
+        load_a(); advance();
+        load_b(0);
+        store_a(As0);
+        store_b(Bs0);
+        __syncthreads();
+        int cur = 0;
+        for (int ks = 0; ks < nk; ++ks) {
+            const bool more = ks + 1 < nk;
+            const float* Ac = As0 + cur * KW * T::A_FLOATS;
+            const float* Bc = Bs0 + cur * KW * T::B_FLOATS;
+            auto prefetch = [&]() __attribute__((always_inline)) { if (more) { load_a(); advance(); load_b(ks + 1); } };
+            // the next step's gathers are issued from inside the MFMA block (between the two k-steps, or half-way through one)
+            if constexpr (KW == 1) ig_compute<T, MF>(Ac, Bc, wm0, wn0, lane, acc, prefetch);
+            else {
+                ig_compute<T, MF>(Ac, Bc, wm0, wn0, lane, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch();
+                __builtin_amdgcn_sched_barrier(0);
+                ig_compute<T, MF>(Ac + T::A_FLOATS, Bc + T::B_FLOATS, wm0, wn0, lane, acc);
+            }
+            // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
+            // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) {
+                store_a(As0 + (cur ^ 1) * KW * T::A_FLOATS);
+                store_b(Bs0 + (cur ^ 1) * KW * T::B_FLOATS);
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
     }
     ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc);
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, int KW = 1>
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, int KW = 1, int PF = 1>
 static int launch_dcn(const ConvArgs& a, hipStream_t s)
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
-    auto kern = dcn_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MF, KW>;
+    auto kern = dcn_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MF, KW, PF>;
     if (a.srcC[0] % (IG_BK * KW) != 0) { cp_set_error("dcn: C=%d is not a multiple of %d", a.srcC[0], IG_BK * KW); return 1; }
     if (a.ldw % BN != 0) { cp_set_error("dcn: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
     const int main_bytes = KW * T::MAIN_BYTES + DCN_MAX_TAPS * BM * 20;
@@ -206,6 +287,7 @@ static int launch_dcn(const ConvArgs& a, hipStream_t s)
     }
     const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
+    cp_note_kernel("dcn_igemm_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N, MF, KW, PF);
     return 0;
 }
 
@@ -243,6 +325,10 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
     hipStream_t s = (hipStream_t)stream;
     int tile = d->tile;
     if (tile == 0) {
+        static const int force = getenv("CP_DCN_TILE") ? atoi(getenv("CP_DCN_TILE")) : 0;      // A/B switch for profiling
+        if (force) tile = force;
+    }
+    if (tile == 0) {
         if (d->ldw % 64 != 0) tile = (d->ldw % 32 == 0) ? 128032 : 0;
         else tile = 64064;      // measured (MI355X, B = 16): 64x64 beats 128x64 by ~11 % on every DLA-34 shape (more, smaller blocks
                                 // interleave gather and MFMA phases better; the kernel is L1-gather-bound, not tile-reuse-bound)
@@ -256,6 +342,11 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
         case 64128: rc = launch_dcn<64, 128, 2, 2, 32>(a, s); break;
         case 2064064: rc = launch_dcn<64, 64, 2, 2, 32, 2>(a, s); break;      // 32-channel (full cache line) gathers
         case 2128064: rc = launch_dcn<128, 64, 2, 2, 32, 2>(a, s); break;
+        case 6064128: rc = (d->ldw % 128 == 0) ? launch_dcn<64, 128, 2, 2, 32>(a, s) : launch_dcn<64, 64, 2, 2, 32>(a, s); break;
+        case 6128128: rc = (d->ldw % 128 == 0) ? launch_dcn<128, 128, 2, 2, 32>(a, s) : launch_dcn<64, 64, 2, 2, 32>(a, s); break;
+        case 5064064: rc = launch_dcn<64, 64, 2, 2, 32, 1, 2>(a, s); break;     // two-deep gather prefetch
+        case 5064128: rc = (d->ldw % 128 == 0) ? launch_dcn<64, 128, 2, 2, 32, 1, 2>(a, s) : launch_dcn<64, 64, 2, 2, 32, 1, 2>(a, s); break;
+        case 5128064: rc = launch_dcn<128, 64, 2, 2, 32, 1, 2>(a, s); break;
         default: CP_CHECK_ARG(false, "dcn_v2: unsupported tile %d (ldw=%d)", tile, d->ldw);
     }
     if (rc) return rc;

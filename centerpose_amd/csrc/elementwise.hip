@@ -63,6 +63,7 @@ extern "C" int cp_maxpool2d_nhwc_f32(const float* in, int inLd, float* out, int 
     const EwRow r = ew_row(B * Ho, Wo, C / 4);
     hipLaunchKernelGGL(maxpool_nhwc_kernel, ew_row_grid(r), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, out, outLd, r,
                        H, W, Ho, Wo, k, s, p);
+    cp_note_kernel("maxpool_nhwc_kernel");
     CP_CHECK_LAUNCH("maxpool_nhwc_kernel");
     return 0;
 }
@@ -115,6 +116,7 @@ extern "C" int cp_dw_deconv_add_nhwc_f32(const float* in, int inLd, const float*
     const EwRow r = ew_row(B * H * f, W * f, C / 4);
     hipLaunchKernelGGL(dw_deconv_add_kernel, ew_row_grid(r), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, w, add,
                        addLd, out, outLd, r, H, W, f, f / 2);
+    cp_note_kernel("dw_deconv_add_kernel");
     CP_CHECK_LAUNCH("dw_deconv_add_kernel");
     return 0;
 }
@@ -151,6 +153,7 @@ extern "C" int cp_sum_up_nhwc_f32(int n, const float* const* src, const int* ld,
     CP_CHECK_ARG((long long)W * (C / 4) * (C / 4) < (1ll << 32) && (long long)B * H < (1ll << 31), "sum_up: row too large");
     const EwRow r = ew_row(B * H, W, C / 4);
     hipLaunchKernelGGL(sum_up_kernel, ew_row_grid(r), dim3(EW_THREADS), 0, (hipStream_t)stream, a, out, outLd, r, H, W, relu);
+    cp_note_kernel("sum_up_kernel");
     CP_CHECK_LAUNCH("sum_up_kernel");
     return 0;
 }

@@ -128,6 +128,7 @@ static int launch_stem(const float* x, const float* w, const float* scale, const
     const int tilesX = cp_cdiv(Wo, TW), tilesY = cp_cdiv(Ho, TH);
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * tilesX * tilesY)), dim3(IG_THREADS), smem, s, x, w, scale, shift, out, B, H, W, Ho,
                        Wo, outLd, relu, tilesX, tilesY);
+    cp_note_kernel("stem7x7_kernel<%d, %d, %d, %d>", NOUT, S, TH, TW);
     return 0;
 }
 

@@ -407,7 +407,7 @@ class Engine:
                 launch.run()
             e1.record()
             e1.synchronize()
-            recs.append(dict(kind=kind, name=name, fn=launch.fn, flops=flops, bytes=nb, ms=e0.elapsed_time(e1) / iters))
+            recs.append(dict(kind=kind, name=name, fn=launch.fn, kernel=launch.kernel, flops=flops, bytes=nb, ms=e0.elapsed_time(e1) / iters))
         return recs
 
     def profile_in_sequence(self, iters=10):
@@ -432,5 +432,5 @@ class Engine:
         recs = []
         for (kind, name, flops, launch), nb, sm in zip(self.launches, nbytes, samples):
             sm.sort()
-            recs.append(dict(kind=kind, name=name, fn=launch.fn, flops=flops, bytes=nb, ms=sm[len(sm) // 2]))
+            recs.append(dict(kind=kind, name=name, fn=launch.fn, kernel=launch.kernel, flops=flops, bytes=nb, ms=sm[len(sm) // 2]))
         return recs

@@ -36,11 +36,12 @@ class Launch:
     struct (or None), the tensor arguments in C order (None = NULL) and the integer arguments.  `run()` only passes
     cached device pointers and the current stream.  The same record is what `plan.py` serialises and what the C plan
     runtime (csrc/plan_runtime.cpp, `cp_plan_*`) replays -- `FN_SIGNATURES` is the contract between the three."""
-    __slots__ = ("fn", "desc", "tensors", "ints", "out_index", "_cfn", "_args")
+    __slots__ = ("fn", "desc", "tensors", "ints", "out_index", "kernel", "_cfn", "_args")
 
     def __init__(self, fn, desc, tensors, ints=(), out_index=-1):
         self.fn, self.desc, self.tensors, self.ints = fn, desc, list(tensors), [int(i) for i in ints]
         self.out_index = out_index % len(self.tensors)
+        self.kernel = None           # device kernel the entry point dispatched to (known after the first run)
         self._cfn = None
         self._args = None
 
@@ -63,6 +64,8 @@ class Launch:
         if self._cfn is None:
             self.bind()
         _lib.check(self._cfn(*self._args, _lib.stream()), self.fn)
+        if self.kernel is None:
+            self.kernel = _lib.lib().cp_last_kernel().decode()
 
 
 def marshal(fn, desc, ptrs, ints):

@@ -21,6 +21,7 @@ extern "C" {
 int cp_abi_version(void);
 const char* cp_target_arch(void);            /* "gfx950" */
 const char* cp_last_error(void);
+const char* cp_last_kernel(void);            /* device kernel (template instantiation) the calling thread launched last */
 
 enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_SIGMOID = 2 };
 
