@@ -50,6 +50,11 @@ ARCH_PRESETS = {  # the MODEL / TEST values of experiments/dla_34_512x512.yaml, 
                "TEST": {"FLIP_TEST": True, "NMS": False, "FIX_RES": True, "TEST_SCALES": [1]}},           # :119-131
     "hrnet": {"MODEL": {"NAME": "hrnet", "HEAD_CONV": 64, "INTERMEDIATE_CHANNEL": 32},
               "TEST": {"FLIP_TEST": True, "NMS": False, "FIX_RES": False, "TEST_SCALES": [1, 2]}},        # :131-143
+    # experiments/mobilenetv3_512x512.yaml, shufflenetV2_512x512.yaml (the other DCN backbones)
+    "mobilenetv3": {"MODEL": {"NAME": "mobilenetv3", "HEAD_CONV": 256, "INTERMEDIATE_CHANNEL": 24},
+                    "TEST": {"FLIP_TEST": True, "NMS": False, "FIX_RES": False, "TEST_SCALES": [1]}},
+    "shufflenetV2": {"MODEL": {"NAME": "shufflenetV2", "HEAD_CONV": 256, "INTERMEDIATE_CHANNEL": 256},
+                     "TEST": {"FLIP_TEST": True, "NMS": False, "FIX_RES": False, "TEST_SCALES": [1]}},
 }
 
 

@@ -31,3 +31,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cp_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// activation codes of the C ABI (include/centerpose_hip.h).  h-swish / h-sigmoid as the reference writes them
+// (lib/models/backbones/mobilenet/mobilenetv3.py:87-96): x * relu6(x + 3) / 6 and relu6(x + 3) / 6, true division.
+#define CP_ACT_NONE_ 0
+#define CP_ACT_RELU_ 1
+#define CP_ACT_SIGMOID_ 2
+#define CP_ACT_HSWISH_ 3
+#define CP_ACT_HSIGMOID_ 4
+__device__ __forceinline__ float cp_act(float v, int act)
+{
+    if (act == CP_ACT_RELU_) return fmaxf(v, 0.f);
+    if (act == CP_ACT_SIGMOID_) return 1.0f / (1.0f + __expf(-v));
+    if (act == CP_ACT_HSWISH_) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
+    if (act == CP_ACT_HSIGMOID_) return fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
+    return v;
+}

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(const Conv
                 else if (sigm) {
                     v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
                     v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
-                }
+                } else if (a.act != CP_ACT_NONE) { v.x = cp_act(v.x, a.act); v.y = cp_act(v.y, a.act); v.z = cp_act(v.z, a.act); v.w = cp_act(v.w, a.act); }
                 *reinterpret_cast<float4*>(a.out + opix * a.outLd + n) = v;
             }
         }
@@ -224,8 +224,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(const Conv
                 if (n < a.Cout) {
                     float v = acc[i][j][r] * a.scale[n] + a.shift[n];
                     if (rrow) v += rrow[n];
-                    if (relu) v = fmaxf(v, 0.f);
-                    else if (sigm) v = 1.0f / (1.0f + __expf(-v));
+                    v = cp_act(v, a.act);
                     orow[n] = v;
                 }
             }

@@ -125,7 +125,7 @@ __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, co
                 else if (sigm) {
                     v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
                     v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
-                }
+                } else if (a.act != CP_ACT_NONE) { v.x = cp_act(v.x, a.act); v.y = cp_act(v.y, a.act); v.z = cp_act(v.z, a.act); v.w = cp_act(v.w, a.act); }
                 *reinterpret_cast<wg_v4*>(a.out + opix * a.outLd + n) = v;
             }
         } else {
@@ -138,8 +138,7 @@ __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, co
                     if (n + k >= a.Cout) break;
                     float w_ = yv[aa][k] * a.scale[n + k] + a.shift[n + k];
                     if (a.res) w_ += a.res[opix * a.resLd + n + k];
-                    if (relu) w_ = fmaxf(w_, 0.f);
-                    else if (sigm) w_ = 1.0f / (1.0f + __expf(-w_));
+                    w_ = cp_act(w_, a.act);
                     a.out[opix * a.outLd + n + k] = w_;
                 }
             }

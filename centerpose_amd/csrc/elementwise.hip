@@ -4,6 +4,9 @@
 //   nearest-upsample sum (+ReLU)    HRNet fuse layers  pose_higher_hrnet.py:217-235
 //   layout transforms               NCHW <-> NHWC (drop-in dcn_v2_forward, tests)
 //   flip-test merge                 multi_pose.py:45-53 + models/utils.py:27-47 (device side, no numpy bounce)
+//   depthwise conv + BN + act       MobileNetV3 Block.conv2 / ShuffleNetV2 banch*  mobilenetv3.py:119-121, shufflenetv2_dcn.py:67-88
+//   squeeze-excite                  SeModule: global average pool, x * se(x) (+ shortcut)  mobilenetv3.py:99-113,141-143
+//   channel shuffle of a concat     ShuffleNetV2 InvertedResidual.forward            shufflenetv2_dcn.py:28-42,94-104
 #include "common.h"
 
 #define EW_THREADS 256
@@ -253,5 +256,153 @@ extern "C" int cp_flip_merge_f32(const float* in, float* out, int C, int H, int 
     hipLaunchKernelGGL(flip_merge_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, in, out, C, H, W, mode,
                        perm);
     CP_CHECK_LAUNCH("flip_merge_kernel");
+    return 0;
+}
+
+// ---- depthwise k x k convolution + folded BN + activation (groups == channels) ---------------------------------------
+// w: [k*k][C] (tap-major, channel contiguous); scale / shift: [C].  Bandwidth-bound: float4 over channels.
+__global__ void dwconv_nhwc_kernel(const float* __restrict__ in, int inLd, const float* __restrict__ w, const float* __restrict__ scale,
+                                   const float* __restrict__ shift, float* __restrict__ out, int outLd, EwRow r, int H, int W, int Ho,
+                                   int Wo, int C, int k, int s, int p, int act)
+{
+    const int e = blockIdx.x * EW_THREADS + threadIdx.x;
+    if (e >= r.rowElems) return;
+    int ox, c4;
+    ew_split(r, e, ox, c4);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c4 * 4), sh = *reinterpret_cast<const float4*>(shift + c4 * 4);
+    for (int row = blockIdx.y; row < r.rows; row += gridDim.y) {
+        const int b = row / Ho, oy = row - b * Ho;                     // uniform
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int ky = 0; ky < k; ++ky) {
+            const int iy = oy * s - p + ky;
+            if (iy < 0 || iy >= H) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ix = ox * s - p + kx;
+                if (ix < 0 || ix >= W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)(b * H + iy) * W + ix) * inLd + c4 * 4);
+                const float4 ww = *reinterpret_cast<const float4*>(w + (size_t)(ky * k + kx) * C + c4 * 4);
+                acc.x = fmaf(v.x, ww.x, acc.x); acc.y = fmaf(v.y, ww.y, acc.y); acc.z = fmaf(v.z, ww.z, acc.z); acc.w = fmaf(v.w, ww.w, acc.w);
+            }
+        }
+        float4 o;
+        o.x = cp_act(acc.x * sc.x + sh.x, act); o.y = cp_act(acc.y * sc.y + sh.y, act);
+        o.z = cp_act(acc.z * sc.z + sh.z, act); o.w = cp_act(acc.w * sc.w + sh.w, act);
+        *reinterpret_cast<float4*>(out + ((size_t)row * Wo + ox) * outLd + c4 * 4) = o;
+    }
+}
+
+extern "C" int cp_dwconv2d_nhwc_f32(const float* in, int inLd, const float* w, const float* scale, const float* shift, float* out,
+                                    int outLd, int B, int H, int W, int C, int k, int s, int p, int act, void* stream)
+{
+    CP_CHECK_ARG(in && w && scale && shift && out && C % 4 == 0 && inLd % 4 == 0 && outLd % 4 == 0, "dwconv: C, ld must be multiples of 4");
+    CP_CHECK_ARG(k >= 1 && s >= 1 && p >= 0 && act >= 0 && act <= CP_ACT_HSIGMOID_, "dwconv: bad k / stride / pad / act");
+    const int Ho = (H + 2 * p - k) / s + 1, Wo = (W + 2 * p - k) / s + 1;
+    CP_CHECK_ARG(Ho > 0 && Wo > 0 && (long long)Wo * (C / 4) * (C / 4) < (1ll << 32) && (long long)B * Ho < (1ll << 31), "dwconv: bad shape");
+    const EwRow r = ew_row(B * Ho, Wo, C / 4);
+    hipLaunchKernelGGL(dwconv_nhwc_kernel, ew_row_grid(r), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, w, scale, shift, out,
+                       outLd, r, H, W, Ho, Wo, C, k, s, p, act);
+    cp_note_kernel("dwconv_nhwc_kernel");
+    CP_CHECK_LAUNCH("dwconv_nhwc_kernel");
+    return 0;
+}
+
+// ---- global average pool: in [B, HW, C] -> out [B, C] (nn.AdaptiveAvgPool2d(1)) -----------------------------------------
+// block (32 channel quads x 8 pixel partitions); grid (channel-quad groups, B)
+__global__ void global_avgpool_kernel(const float* __restrict__ in, int inLd, float* __restrict__ out, int outLd, int HW, int C4)
+{
+    __shared__ float4 part[8][32];
+    const int cq = threadIdx.x & 31, pp = threadIdx.x >> 5, c4 = blockIdx.x * 32 + cq, b = blockIdx.y;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 < C4)
+        for (int p = pp; p < HW; p += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(in + ((size_t)b * HW + p) * inLd + c4 * 4);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+    part[pp][cq] = acc;
+    __syncthreads();
+    if (pp == 0 && c4 < C4) {
+#pragma unroll
+        for (int j = 1; j < 8; ++j) { const float4 v = part[j][cq]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+        const float n = (float)HW;
+        *reinterpret_cast<float4*>(out + (size_t)b * outLd + c4 * 4) = make_float4(acc.x / n, acc.y / n, acc.z / n, acc.w / n);
+    }
+}
+
+extern "C" int cp_global_avgpool_nhwc_f32(const float* in, int inLd, float* out, int outLd, int B, int HW, int C, void* stream)
+{
+    CP_CHECK_ARG(in && out && C % 4 == 0 && inLd % 4 == 0 && outLd % 4 == 0 && B > 0 && HW > 0 && B <= 65535, "global_avgpool: bad arguments");
+    hipLaunchKernelGGL(global_avgpool_kernel, dim3((unsigned)cp_cdiv(C / 4, 32), (unsigned)B), dim3(256), 0, (hipStream_t)stream, in, inLd,
+                       out, outLd, HW, C / 4);
+    cp_note_kernel("global_avgpool_kernel");
+    CP_CHECK_LAUNCH("global_avgpool_kernel");
+    return 0;
+}
+
+// ---- squeeze-excite apply: out[b,p,c] = x[b,p,c] * se[b,c] (+ add[b,p,c])   (mobilenetv3.py:112-113,141-143) ------------
+__global__ void scale_add_kernel(const float* __restrict__ x, int xLd, const float* __restrict__ se, int seLd, const float* __restrict__ add,
+                                 int addLd, float* __restrict__ out, int outLd, EwRow r, int H)
+{
+    const int e = blockIdx.x * EW_THREADS + threadIdx.x;
+    if (e >= r.rowElems) return;
+    int px, c4;
+    ew_split(r, e, px, c4);
+    for (int row = blockIdx.y; row < r.rows; row += gridDim.y) {
+        const int b = row / H;                                          // uniform
+        const size_t pix = (size_t)row * (r.rowElems / r.C4) + px;
+        const float4 v = *reinterpret_cast<const float4*>(x + pix * xLd + c4 * 4);
+        const float4 g = *reinterpret_cast<const float4*>(se + (size_t)b * seLd + c4 * 4);
+        float4 o = make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+        if (add) {
+            const float4 a4 = *reinterpret_cast<const float4*>(add + pix * addLd + c4 * 4);
+            o.x += a4.x; o.y += a4.y; o.z += a4.z; o.w += a4.w;
+        }
+        *reinterpret_cast<float4*>(out + pix * outLd + c4 * 4) = o;
+    }
+}
+
+extern "C" int cp_scale_add_nhwc_f32(const float* x, int xLd, const float* se, int seLd, const float* add, int addLd, float* out, int outLd,
+                                     int B, int H, int W, int C, void* stream)
+{
+    CP_CHECK_ARG(x && se && out && C % 4 == 0 && xLd % 4 == 0 && seLd % 4 == 0 && outLd % 4 == 0 && (!add || addLd % 4 == 0),
+                 "scale_add: C, ld must be multiples of 4");
+    CP_CHECK_ARG((long long)W * (C / 4) * (C / 4) < (1ll << 32) && (long long)B * H < (1ll << 31), "scale_add: row too large");
+    const EwRow r = ew_row(B * H, W, C / 4);
+    hipLaunchKernelGGL(scale_add_kernel, ew_row_grid(r), dim3(EW_THREADS), 0, (hipStream_t)stream, x, xLd, se, seLd, add, addLd, out, outLd,
+                       r, H);
+    cp_note_kernel("scale_add_kernel");
+    CP_CHECK_LAUNCH("scale_add_kernel");
+    return 0;
+}
+
+// ---- channel_shuffle(cat(x1, x2), groups = 2)   (shufflenetv2_dcn.py:28-42,103-104) --------------------------------------
+// x1, x2: h channels each.  The shuffled tensor has 2h logical channels, logical 2i = x1[i], 2i+1 = x2[i].  It is stored
+// as TWO halves of hp >= h physical channels each (hp % 16 == 0: the next block splits it down the middle, x[:, :h] /
+// x[:, h:], and every kernel wants 16-aligned channel runs): logical c < h -> physical c, c >= h -> hp + (c - h); the
+// padding channels are written as zeros.
+__global__ void shuffle_concat_kernel(const float* __restrict__ x1, int ld1, const float* __restrict__ x2, int ld2, float* __restrict__ out,
+                                      int outLd, long long npix, int h, int hp)
+{
+    const long long total = npix * 2 * hp;
+    for (long long e = (long long)blockIdx.x * EW_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * EW_THREADS) {
+        const long long pix = e / (2 * hp);
+        const int pc = (int)(e - pix * 2 * hp);
+        const int half = pc >= hp, q = pc - half * hp;
+        float v = 0.f;
+        if (q < h) {
+            const int L = half * h + q;                                  // logical channel
+            v = (L & 1) ? x2[pix * ld2 + (L >> 1)] : x1[pix * ld1 + (L >> 1)];
+        }
+        out[pix * outLd + pc] = v;
+    }
+}
+
+extern "C" int cp_shuffle_concat_nhwc_f32(const float* x1, int ld1, const float* x2, int ld2, float* out, int outLd, long long npix, int h,
+                                          int hp, void* stream)
+{
+    CP_CHECK_ARG(x1 && x2 && out && h > 0 && hp >= h && outLd >= 2 * hp && npix > 0, "shuffle_concat: bad arguments");
+    hipLaunchKernelGGL(shuffle_concat_kernel, dim3(ew_grid(npix * 2 * hp)), dim3(EW_THREADS), 0, (hipStream_t)stream, x1, ld1, x2, ld2, out,
+                       outLd, npix, h, hp);
+    cp_note_kernel("shuffle_concat_kernel");
+    CP_CHECK_LAUNCH("shuffle_concat_kernel");
     return 0;
 }

@@ -188,12 +188,7 @@ __device__ __forceinline__ void ig_compute(const float* As, const float* Bs, int
     ig_compute<T, MF>(As, Bs, wm0, wn0, lane, acc, [] {});
 }
 
-__device__ __forceinline__ float ig_act(float v, int act)
-{
-    if (act == CP_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == CP_ACT_SIGMOID) return 1.0f / (1.0f + __expf(-v));
-    return v;
-}
+__device__ __forceinline__ float ig_act(float v, int act) { return cp_act(v, act); }
 
 // ---- epilogue --------------------------------------------------------------------------------
 template <class T, int BM, int BN, int MF>
@@ -247,13 +242,12 @@ __device__ __forceinline__ void ig_epilogue(const ConvArgs& a, float* smem, int 
                 else if (sigm) {
                     v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
                     v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
-                }
+                } else if (a.act != CP_ACT_NONE) { v.x = cp_act(v.x, a.act); v.y = cp_act(v.y, a.act); v.z = cp_act(v.z, a.act); v.w = cp_act(v.w, a.act); }
                 *reinterpret_cast<float4*>(a.out + opix * a.outLd + n) = v;
             }
         }
     } else if (!a.outNCHW) {
         const bool dense = (a.osy == 1 && a.osx == 1 && ooy == 0 && oox == 0 && a.OH == a.Ho && a.OW == a.Wo);
-        const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
 #pragma unroll
         for (int i = 0; i < T::TM; ++i) {
 #pragma unroll
@@ -273,8 +267,7 @@ __device__ __forceinline__ void ig_epilogue(const ConvArgs& a, float* smem, int 
                     if (n < a.Cout) {
                         float v = acc[i][j][r] * a.scale[n] + a.shift[n];
                         if (rrow) v += rrow[n];
-                        if (relu) v = fmaxf(v, 0.f);
-                        else if (sigm) v = 1.0f / (1.0f + __expf(-v));
+                        v = cp_act(v, a.act);
                         orow[n] = v;
                     }
                 }

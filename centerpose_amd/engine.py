@@ -77,11 +77,47 @@ class PlanBuilder(nets.Graph):
         return self.pool.bytes
 
     # -- helpers ------------------------------------------------------------------------------
-    def buf(self, H, W, C):
-        slot = self.pool.take(self.B * H * W * C)
-        act = Act(H, W, C, slot[: self.B * H * W * C].view(self.B, H, W, C))
+    def buf(self, H, W, C, split=None):
+        """Activation with C logical channels; the tensor holds them padded to a multiple of 16 (`split` = (h, hp): two
+        halves of hp physical channels).  Every launch writes the padding channels as zeros (zero weight rows, zero
+        scale / shift), so consumers can read whole 16-channel k-steps."""
+        Cp = 2 * split[1] if split else ops.round_up(C, 16)
+        slot = self.pool.take(self.B * H * W * Cp)
+        act = Act(H, W, C, slot[: self.B * H * W * Cp].view(self.B, H, W, Cp), split)
         weakref.finalize(act, self.pool.give, slot)       # the walk has dropped the activation: its storage may be reused
         return act
+
+    @staticmethod
+    def cmap(a):
+        """physical channel index of every logical channel of activation `a` (identity unless split)."""
+        if a.split:
+            h, hp = a.split
+            return list(range(h)) + list(range(hp, hp + h))
+        return list(range(a.C))
+
+    def expand_in(self, w, xs):
+        """conv weight [Co, sum Ci, kh, kw] over the LOGICAL input channels of the sources -> the same over their physical
+        channels (zeros at the padding), so that k = (tap, physical channel) matches what the kernels read."""
+        if all(a.t.shape[3] == a.C and not a.split for a in xs):
+            return w
+        out = torch.zeros((w.shape[0], sum(a.t.shape[3] for a in xs)) + tuple(w.shape[2:]), dtype=w.dtype, device=w.device)
+        lo = po = 0
+        for a in xs:
+            idx = torch.tensor(self.cmap(a), device=w.device) + po
+            out[:, idx] = w[:, lo:lo + a.C]
+            lo, po = lo + a.C, po + a.t.shape[3]
+        return out
+
+    def expand_vec(self, v, a, fill=0.0):
+        """per-channel vector over the logical channels of `a` -> over its physical channels."""
+        out = torch.full((a.t.shape[3],), fill, dtype=torch.float32, device=v.device)
+        out[torch.tensor(self.cmap(a), device=v.device)] = v.float()
+        return out
+
+    @staticmethod
+    def act_code(relu):
+        return {False: ops.ACT_NONE, None: ops.ACT_NONE, True: ops.ACT_RELU, "relu": ops.ACT_RELU, "hswish": ops.ACT_HSWISH,
+                "hsigmoid": ops.ACT_HSIGMOID}[relu]
 
     def w(self, key):
         return self.sd[key].to(self.dev, torch.float32)
@@ -103,22 +139,23 @@ class PlanBuilder(nets.Graph):
         x = xs[0]
         Ho, Wo = (x.H + 2 * pad - k) // stride + 1, (x.W + 2 * pad - k) // stride + 1
         out = self.buf(Ho, Wo, co)
-        if stem and k == 7 and pad == 3 and co in (16, 64) and res is None and bn:
+        if stem and k == 7 and pad == 3 and co in (16, 64) and res is None and bn and relu in (True, False):
             # dedicated 7x7 stem kernel (NCHW 3-channel input window staged once in LDS)
             wp7 = ops.pack_stem7_weight(self.w(conv + ".weight"))
             sc7, sh7 = ops.fold_bn(co, self.bn(bn), self.w(conv + ".bias") if bias else None, self.dev)
             self.add("conv", conv, 2 * Ho * Wo * co * 3 * 49, ops.stem7x7_launch(xs[0].t, wp7, sc7, sh7, out.t, stride, relu))
             return out
-        wp = ops.pack_conv_weight(self.w(conv + ".weight"), stem=stem)
+        w = self.w(conv + ".weight")
+        wp = ops.pack_conv_weight(w if stem else self.expand_in(w, xs), stem=stem)
         sc, sh = ops.fold_bn(co, self.bn(bn) if bn else None, self.w(conv + ".bias") if bias else None, self.dev)
         srcs = [a.t for a in xs]
         rt = res.t if res is not None else None
-        act = ops.ACT_RELU if relu else ops.ACT_NONE
         ci = sum(a.C for a in xs)
-        u = None if stem else self.wino(wp, ci, co, k, stride, pad, len(xs))
+        cip = ci if stem else sum(a.t.shape[3] for a in xs)               # physical K per tap
+        u = None if stem else self.wino(wp, cip, co, k, stride, pad, len(xs))
         self.add("wino" if u is not None else "conv", conv, 2 * Ho * Wo * co * ci * k * k,
-                 ops.conv2d_launch(srcs, wp, sc, sh, out.t, kh=k, kw=k, stride=stride, pad=pad, cout=co, act=act, res=rt,
-                                   in_nchw=stem, wino=u))
+                 ops.conv2d_launch(srcs, wp, sc, sh, out.t, kh=k, kw=k, stride=stride, pad=pad, cout=out.t.shape[3],
+                                   act=self.act_code(relu), res=rt, in_nchw=stem, wino=u))
         return out
 
     def emit_maxpool(self, x, k, s, p):
@@ -134,25 +171,65 @@ class PlanBuilder(nets.Graph):
         self._pool_cache[key] = (weakref.ref(x), weakref.ref(out))
         return out
 
-    def emit_dcn(self, x, name, co):
+    def emit_dcn(self, x, conv, bn, co):
         om = self.buf(x.H, x.W, 32)
-        wom = ops.pack_conv_weight(self.w(name + ".conv.conv_offset_mask.weight"))     # [9C, 32]
-        som, hom = ops.fold_bn(27, None, self.w(name + ".conv.conv_offset_mask.bias"), self.dev)
+        wom = ops.pack_conv_weight(self.expand_in(self.w(conv + ".conv_offset_mask.weight"), [x]))     # [9C, 32]
+        som, hom = ops.fold_bn(27, None, self.w(conv + ".conv_offset_mask.bias"), self.dev)
         som[27:] = 0.0   # pad channels are written as exact zeros
         out = self.buf(x.H, x.W, co)
-        wp = ops.pack_conv_weight(self.w(name + ".conv.weight"))
-        sc, sh = ops.fold_bn(co, self.bn(name + ".actf.0"), self.w(name + ".conv.bias"), self.dev)
-        uom = self.wino(wom, x.C, 32)
-        self.add("wino" if uom is not None else "conv", name + ".conv.conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9,
+        wp = ops.pack_conv_weight(self.expand_in(self.w(conv + ".weight"), [x]))
+        sc, sh = ops.fold_bn(co, self.bn(bn), self.w(conv + ".bias"), self.dev)
+        uom = self.wino(wom, x.t.shape[3], 32)
+        self.add("wino" if uom is not None else "conv", conv + ".conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9,
                  ops.conv2d_launch([x.t], wom, som, hom, om.t, kh=3, kw=3, stride=1, pad=1, cout=32, wino=uom))
-        self.add("dcn", name + ".conv", 2 * x.H * x.W * co * x.C * 9,
-                 ops.dcn_v2_launch(x.t, om.t, wp, sc, sh, out.t, cout=co, om_sigmoid=True, act=ops.ACT_RELU))
+        self.add("dcn", conv, 2 * x.H * x.W * co * x.C * 9,
+                 ops.dcn_v2_launch(x.t, om.t, wp, sc, sh, out.t, cout=out.t.shape[3], om_sigmoid=True, act=ops.ACT_RELU))
         return out
 
     def emit_up_add(self, x, wname, f, add):
         out = self.buf(x.H * f, x.W * f, x.C)
         wk = ops.pack_dw_deconv_weight(self.w(wname + ".weight"))
+        if wk.shape[1] != x.t.shape[3]:                                   # zero taps for the padding channels
+            wk = torch.cat([wk, wk.new_zeros((wk.shape[0], x.t.shape[3] - wk.shape[1]))], 1).contiguous()
         self.add("up", wname, 2 * out.H * out.W * x.C * 4, ops.dw_deconv_add_launch(x.t, wk, add.t, out.t, f))
+        return out
+
+    # -- MobileNetV3 / ShuffleNetV2 building blocks -----------------------------------
+    def emit_dwconv(self, x, conv, bn, k, stride, act):
+        Ho, Wo = (x.H + 2 * (k // 2) - k) // stride + 1, (x.W + 2 * (k // 2) - k) // stride + 1
+        out = self.buf(Ho, Wo, x.C, x.split)
+        g, b, mean, var = self.bn(bn)
+        scale = g / torch.sqrt(var + ops.BN_EPS)
+        shift = b - mean * scale
+        wk = ops.pack_dw_weight(self.w(conv + ".weight"))                       # [k*k, C] over the logical channels
+        wkp = torch.stack([self.expand_vec(row, x) for row in wk], 0).contiguous()
+        self.add("dw", conv, 2 * Ho * Wo * x.C * k * k,
+                 ops.dwconv2d_launch(x.t, wkp, self.expand_vec(scale, x), self.expand_vec(shift, x), out.t, k, stride, k // 2,
+                                     self.act_code(act)))
+        return out
+
+    def emit_se(self, x, p, red):
+        """SeModule (mobilenetv3.py:99-113): avg-pool -> 1x1 + BN + ReLU -> 1x1 + BN + h-sigmoid, on [B,1,1,C]."""
+        pooled = self.buf(1, 1, x.C)
+        self.add("pool", p + ".0", 0, ops.global_avgpool_launch(x.t, pooled.t))
+        mid = self.emit_conv([pooled], p + ".1", p + ".2", False, red, 1, 1, 0, True, None, False)
+        return self.emit_conv([mid], p + ".4", p + ".5", False, x.C, 1, 1, 0, "hsigmoid", None, False)
+
+    def emit_scale_add(self, x, se, add):
+        out = self.buf(x.H, x.W, x.C)
+        self.add("se", "se.scale", 0, ops.scale_add_launch(x.t, se.t, add.t if add is not None else None, out.t))
+        return out
+
+    def emit_half(self, x, which):
+        """x[:, :h] / x[:, h:] of a channel-shuffled tensor: a view of one of its two physical halves (no copy)."""
+        h, hp = x.split
+        return Act(x.H, x.W, h, x.t[..., which * hp:(which + 1) * hp], parent=x)
+
+    def emit_shuffle(self, x1, x2):
+        h = x1.C
+        hp = ops.round_up(h, 16)
+        out = self.buf(x1.H, x1.W, 2 * h, (h, hp))
+        self.add("shuffle", "channel_shuffle", 0, ops.shuffle_concat_launch(x1.t, x2.t, out.t, h, hp))
         return out
 
     def emit_deconv4(self, x, wname, bn, co):
@@ -186,11 +263,11 @@ class PlanBuilder(nets.Graph):
             mid = self.buf(H, W, hc)
         else:
             mid = self.buf(H, W, 6 * hc)
-            w3 = torch.cat([self.w("%s.%s.0.weight" % (p, h)) for h, _ in nets.HEADS], 0)
+            w3 = self.expand_in(torch.cat([self.w("%s.%s.0.weight" % (p, h)) for h, _ in nets.HEADS], 0), [feat])
             b3 = torch.cat([self.w("%s.%s.0.bias" % (p, h)) for h, _ in nets.HEADS], 0)
             wp3 = ops.pack_conv_weight(w3)
             sc3, sh3 = ops.fold_bn(6 * hc, None, b3, self.dev)
-            u3 = self.wino(wp3, feat.C, 6 * hc)
+            u3 = self.wino(wp3, feat.t.shape[3], 6 * hc)
             self.add("wino" if u3 is not None else "conv", p + ".*.0", 2 * H * W * 6 * hc * feat.C * 9,
                      ops.conv2d_launch([ft], wp3, sc3, sh3, mid.t, kh=3, kw=3, stride=1, pad=1, cout=6 * hc, act=ops.ACT_RELU, wino=u3))
         for i, (h, n) in enumerate(nets.HEADS):
@@ -199,9 +276,9 @@ class PlanBuilder(nets.Graph):
             sc, sh = ops.fold_bn(n, None, self.w("%s.%s.2.bias" % (p, h)), self.dev)
             act = ops.ACT_SIGMOID if h in self.sigmoid_heads else ops.ACT_NONE
             if per_head:
-                wp3h = ops.pack_conv_weight(self.w("%s.%s.0.weight" % (p, h)))
+                wp3h = ops.pack_conv_weight(self.expand_in(self.w("%s.%s.0.weight" % (p, h)), [feat]))
                 sc3h, sh3h = ops.fold_bn(hc, None, self.w("%s.%s.0.bias" % (p, h)), self.dev)
-                u3h = self.wino(wp3h, feat.C, hc)
+                u3h = self.wino(wp3h, feat.t.shape[3], hc)
                 self.add("wino" if u3h is not None else "conv", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9,
                          ops.conv2d_launch([ft], wp3h, sc3h, sh3h, mid.t, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU,
                                            wino=u3h))

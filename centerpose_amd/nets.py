@@ -7,6 +7,8 @@
 * FLOP accounting          -- algorithmic 2*MAC per launch for the roofline numbers.
 
 Structure follows the reference modules (they are *not* imported):
+  mobilenetv3   lib/models/backbones/mobilenet/mobilenetv3.py   Block :116-144, SeModule :99-113, MobileNetV3 :160-222
+  shufflenetV2  lib/models/backbones/shufflenetv2_dcn.py        InvertedResidual :55-104, ShuffleNetV2 :106-222
   dla_34   lib/models/backbones/pose_dla_dcn.py   DLA :222-290, Tree :166-219, Root :145-163,
            BasicBlock :29-57, DeformConv :336-348, IDAUp :351-377, DLAUp :381-404, DLASeg :437-447
   res_50   lib/models/backbones/msra_resnet.py    Bottleneck :64-102, PoseResNet :113-208
@@ -17,15 +19,18 @@ from collections import OrderedDict
 
 HEADS = (("hm", 1), ("wh", 2), ("hps", 34), ("reg", 2), ("hm_hp", 17), ("hp_offset", 2))
 # (INTERMEDIATE_CHANNEL, HEAD_CONV) per experiments/*.yaml
-ARCH_HEAD = {"dla_34": (64, 256), "res_50": (256, 64), "hrnet": (32, 64)}
+ARCH_HEAD = {"dla_34": (64, 256), "res_50": (256, 64), "hrnet": (32, 64), "mobilenetv3": (24, 256), "shufflenetV2": (256, 256)}
 
 
 class Act:
-    """A feature map in the plan: NHWC, [B,H,W,C]; ``t`` is the device tensor (None in spec mode)."""
-    __slots__ = ("H", "W", "C", "t", "__weakref__")      # weak-referenceable: engine.BufferPool reclaims a dead activation's storage
+    """A feature map in the plan: NHWC, [B,H,W,C]; ``t`` is the device tensor (None in spec mode).  ``C`` counts the
+    LOGICAL channels; the tensor holds them zero-padded to a multiple of 16 (``split`` = (h, hp): two halves of h logical
+    channels stored in hp physical ones each -- the channel-shuffled tensors of ShuffleNetV2)."""
+    __slots__ = ("H", "W", "C", "t", "split", "parent", "__weakref__")      # weak-referenceable: engine.BufferPool reclaims a dead activation's storage
 
-    def __init__(self, H, W, C, t=None):
-        self.H, self.W, self.C, self.t = H, W, C, t
+    def __init__(self, H, W, C, t=None, split=None, parent=None):
+        self.H, self.W, self.C, self.t, self.split = H, W, C, t, split
+        self.parent = parent          # a view keeps the activation that owns its storage alive
 
 
 class Graph:
@@ -54,7 +59,7 @@ class Graph:
     def emit_maxpool(self, x, k, s, p):
         return Act((x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1, x.C)
 
-    def emit_dcn(self, x, name, co):
+    def emit_dcn(self, x, conv, bn, co):
         return Act(x.H, x.W, co)
 
     def emit_up_add(self, x, wname, f, add):
@@ -69,6 +74,21 @@ class Graph:
     def emit_head(self, feat, p, hc):
         return None
 
+    def emit_dwconv(self, x, conv, bn, k, stride, act):
+        return Act((x.H + 2 * (k // 2) - k) // stride + 1, (x.W + 2 * (k // 2) - k) // stride + 1, x.C, split=x.split)
+
+    def emit_se(self, x, p, red):
+        return Act(1, 1, x.C)
+
+    def emit_scale_add(self, x, se, add):
+        return Act(x.H, x.W, x.C)
+
+    def emit_shuffle(self, x1, x2):
+        return Act(x1.H, x1.W, 2 * x1.C, split=(x1.C, (x1.C + 15) // 16 * 16))
+
+    def emit_half(self, x, which):
+        return Act(x.H, x.W, x.split[0])
+
     # ---- building blocks ------------------------------------------------------------------
     def conv(self, xs, name, bn, co, k, stride=1, pad=0, relu=False, res=None, bias=False, stem=False):
         xs = xs if isinstance(xs, (list, tuple)) else [xs]
@@ -82,11 +102,23 @@ class Graph:
 
     def deform(self, x, name, co):
         """DeformConv = conv_offset_mask (3x3, 27 ch, bias) -> DCNv2 3x3 (bias) -> BN -> ReLU."""
-        self.p_bn(name + ".actf.0", co)
-        self.p_conv(name + ".conv", co, x.C, 3, True)
-        self.p_conv(name + ".conv.conv_offset_mask", 27, x.C, 3, True)
-        out = self.emit_dcn(x, name, co)
+        return self.dcn_bn_relu(x, name + ".conv", name + ".actf.0", co)
+
+    def dcn_bn_relu(self, x, conv, bn, co):
+        """DCN module `conv` (weight, bias, conv_offset_mask.*; dcn_v2.py:95-127) + BatchNorm `bn` + ReLU."""
+        self.p_bn(bn, co)
+        self.p_conv(conv, co, x.C, 3, True)
+        self.p_conv(conv + ".conv_offset_mask", 27, x.C, 3, True)
+        out = self.emit_dcn(x, conv, bn, co)
         self.flops += 2 * x.H * x.W * x.C * 9 * (27 + co)
+        return out
+
+    def dwconv(self, x, name, bn, k, stride, act=None):
+        """depthwise k x k conv (groups == channels, pad k // 2, no bias) + BN (+ activation)."""
+        self.spec[name + ".weight"] = (x.C, 1, k, k)
+        self.p_bn(bn, x.C)
+        out = self.emit_dwconv(x, name, bn, k, stride, act)
+        self.flops += 2 * out.H * out.W * x.C * k * k
         return out
 
     def up_add(self, x, wname, f, add):
@@ -241,6 +273,74 @@ class Graph:
             ys, pre = xs, chans
         return ys[0]
 
+    # ---- MobileNetV3 (large) + IDAUp ------------------------------------------------------------
+    def _mb_block(self, x, p, k, cin, cexp, cout, act, se, stride):
+        """mobilenetv3.py:116-144: expand 1x1 -> depthwise k x k -> project 1x1 (+ SE) (+ shortcut when stride 1)."""
+        h = self.conv(x, p + ".conv1", p + ".bn1", cexp, 1, relu=act)
+        h = self.dwconv(h, p + ".conv2", p + ".bn2", k, stride, act)
+        sc = None
+        if stride == 1:
+            sc = x if cin == cout else self.conv(x, p + ".shortcut.0", p + ".shortcut.1", cout, 1)
+        if not se:
+            return self.conv(h, p + ".conv3", p + ".bn3", cout, 1, res=sc)
+        h = self.conv(h, p + ".conv3", p + ".bn3", cout, 1)
+        red = cout // 4
+        self.p_conv(p + ".se.se.1", red, cout, 1); self.p_bn(p + ".se.se.2", red)
+        self.p_conv(p + ".se.se.4", cout, red, 1); self.p_bn(p + ".se.se.5", cout)
+        self.flops += 2 * 2 * cout * red
+        g = self.emit_se(h, p + ".se.se", red)
+        return self.emit_scale_add(h, g, sc)
+
+    def mobilenetv3(self, x, p="backbone_model"):
+        x = self.conv(x, p + ".conv1", p + ".bn1", 16, 3, 2, 1, relu="hswish", stem=True)
+        R, HS = "relu", "hswish"
+        stages = [[(3, 16, 16, 16, R, 0, 1), (3, 16, 64, 24, R, 0, 2), (3, 24, 72, 24, R, 0, 1)],
+                  [(5, 24, 72, 40, R, 1, 2), (5, 40, 120, 40, R, 1, 1), (5, 40, 120, 40, R, 1, 1)],
+                  [(3, 40, 240, 80, HS, 0, 2), (3, 80, 200, 80, HS, 0, 1), (3, 80, 184, 80, HS, 0, 1), (3, 80, 184, 80, HS, 0, 1),
+                   (3, 80, 480, 112, HS, 1, 1), (3, 112, 672, 112, HS, 1, 1), (5, 112, 672, 160, HS, 1, 1)],
+                  [(5, 160, 672, 160, HS, 1, 2), (5, 160, 960, 160, HS, 1, 1)]]
+        outs = []
+        for si, blocks in enumerate(stages):
+            for bi, (k, ci, ce, co, act, se, st) in enumerate(blocks):
+                x = self._mb_block(x, "%s.bneck%d.%d" % (p, si, bi), k, ci, ce, co, act, se, st)
+            outs.append(x)
+        outs[3] = self.conv(outs[3], p + ".conv2", p + ".bn2", 960, 1, relu="hswish")
+        self._ida_up(p + ".ida_up", outs, 0, 4, 24, up_f=[1, 2, 4, 8])          # mobilenetv3.py:190-191,215-220
+        return outs[-1]
+
+    # ---- ShuffleNetV2 1.0x + three (DCN, dense deconv) stages -----------------------------------
+    def _shuffle_block(self, x, p, cin, cout, stride, benchmodel):
+        """shufflenetv2_dcn.py:55-104.  Returns channel_shuffle(cat(left, right), 2) in the split layout."""
+        h = cout // 2
+        if benchmodel == 1:
+            left = self.emit_half(x, 0)
+            r = self.conv(self.emit_half(x, 1), p + ".banch2.0", p + ".banch2.1", h, 1, relu=True)
+        else:
+            left = self.dwconv(x, p + ".banch1.0", p + ".banch1.1", 3, stride)
+            left = self.conv(left, p + ".banch1.2", p + ".banch1.3", h, 1, relu=True)
+            r = self.conv(x, p + ".banch2.0", p + ".banch2.1", h, 1, relu=True)
+        r = self.dwconv(r, p + ".banch2.3", p + ".banch2.4", 3, stride)
+        r = self.conv(r, p + ".banch2.5", p + ".banch2.6", h, 1, relu=True)
+        return self.emit_shuffle(left, r)
+
+    def shufflenetv2(self, x, p="backbone_model"):
+        x = self.conv(x, p + ".conv1.0", p + ".conv1.1", 24, 3, 2, 1, relu=True, stem=True)
+        x = self.emit_maxpool(x, 3, 2, 1)
+        cin, i = 24, 0
+        for cout, rep in zip([116, 232, 464], [4, 8, 4]):
+            for j in range(rep):
+                x = self._shuffle_block(x, "%s.features.%d" % (p, i), cin, cout, 2 if j == 0 else 1, 2 if j == 0 else 1)
+                cin, i = cout, i + 1
+        for d in range(3):                                                  # shufflenetv2_dcn.py:172-206
+            q = "%s.deconv_layers." % p
+            x = self.dcn_bn_relu(x, q + str(6 * d), q + str(6 * d + 1), 256)
+            self.spec[q + str(6 * d + 3) + ".weight"] = (256, 256, 4, 4)
+            self.p_bn(q + str(6 * d + 4), 256)
+            x_in = x
+            x = self.emit_deconv4(x, q + str(6 * d + 3), q + str(6 * d + 4), 256)
+            self.flops += 2 * x_in.H * x_in.W * 256 * 256 * 16
+        return x
+
     # ---- head --------------------------------------------------------------------------------
     def head(self, feat, hc, p="head_model"):
         for h, n in HEADS:
@@ -252,7 +352,8 @@ class Graph:
     def network(self, arch, x, head_conv=None):
         base = canonical_arch(arch)
         inter, hc = ARCH_HEAD[base]
-        feat = {"dla_34": self.dla34, "res_50": self.res50, "hrnet": self.hrnet_w32}[base](x)
+        feat = {"dla_34": self.dla34, "res_50": self.res50, "hrnet": self.hrnet_w32, "mobilenetv3": self.mobilenetv3,
+                "shufflenetV2": self.shufflenetv2}[base](x)
         assert feat.C == inter
         return self.head(feat, head_conv or hc)
 
@@ -266,7 +367,11 @@ def canonical_arch(arch):
         return "res_50"
     if a.startswith("hrnet"):
         return "hrnet"
-    raise ValueError("unsupported arch %r (the MI355X hot path covers dla_34, res_50, hrnet)" % arch)
+    if a == "mobilenetv3":
+        return "mobilenetv3"
+    if a == "shufflenetv2":
+        return "shufflenetV2"
+    raise ValueError("unsupported arch %r (the MI355X hot path covers dla_34, res_50, hrnet, mobilenetv3, shufflenetV2)" % arch)
 
 
 def param_spec(arch, H=512, W=512, head_conv=None):

@@ -10,7 +10,7 @@ import torch
 
 from . import _lib
 
-ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_SIGMOID, ACT_HSWISH, ACT_HSIGMOID = 0, 1, 2, 3, 4
 BN_EPS = 1e-5  # nn.BatchNorm2d default (reference never overrides it)
 
 
@@ -88,11 +88,20 @@ def marshal(fn, desc, ptrs, ints):
         lds = (ctypes.c_int * 4)(*ints[1:5])
         shs = (ctypes.c_int * 4)(*ints[5:9])
         return [ints[0], srcs, lds, shs, ptrs[4]] + ints[9:]
+    if fn == "cp_dwconv2d_nhwc_f32":              # ptrs: in, w, scale, shift, out; ints: inLd, outLd, B, H, W, C, k, s, p, act
+        return [ptrs[0], ints[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4]] + ints[1:]
+    if fn == "cp_global_avgpool_nhwc_f32":        # ptrs: in, out; ints: inLd, outLd, B, HW, C
+        return [ptrs[0], ints[0], ptrs[1]] + ints[1:]
+    if fn == "cp_scale_add_nhwc_f32":             # ptrs: x, se, add, out; ints: xLd, seLd, addLd, outLd, B, H, W, C
+        return [ptrs[0], ints[0], ptrs[1], ints[1], ptrs[2], ints[2], ptrs[3]] + ints[3:]
+    if fn == "cp_shuffle_concat_nhwc_f32":        # ptrs: x1, x2, out; ints: ld1, ld2, outLd, npix, h, hp
+        return [ptrs[0], ints[0], ptrs[1], ints[1], ptrs[2], ints[2], ctypes.c_longlong(ints[3]), ints[4], ints[5]]
     raise ValueError("unknown launch function %r" % fn)
 
 
 FN_IDS = {"cp_conv2d_f32": 1, "cp_conv3x3_winograd_f32": 2, "cp_dcn_v2_f32": 3, "cp_stem7x7_f32": 4,
-          "cp_maxpool2d_nhwc_f32": 5, "cp_dw_deconv_add_nhwc_f32": 6, "cp_sum_up_nhwc_f32": 7}
+          "cp_maxpool2d_nhwc_f32": 5, "cp_dw_deconv_add_nhwc_f32": 6, "cp_sum_up_nhwc_f32": 7, "cp_dwconv2d_nhwc_f32": 8,
+          "cp_global_avgpool_nhwc_f32": 9, "cp_scale_add_nhwc_f32": 10, "cp_shuffle_concat_nhwc_f32": 11}
 
 
 def pad_rows(t, ldw):
@@ -278,6 +287,58 @@ def dw_deconv_add_launch(x, wk, add, out, f):
 
 def dw_deconv_add(x, wk, add, out, f):
     dw_deconv_add_launch(x, wk, add, out, f).run()
+    return out
+
+
+def pack_dw_weight(w):
+    """depthwise Conv2d weight [C,1,k,k] -> [k*k, C]"""
+    C, _, k, _ = w.shape
+    return w.reshape(C, k * k).t().contiguous().float()
+
+
+def dwconv2d_launch(x, wk, scale, shift, out, k, stride, pad, act=ACT_NONE):
+    """depthwise k x k conv + folded BN + act; x NHWC [B,H,W,C], wk [k*k, C], out NHWC [B,Ho,Wo,C]."""
+    B, H, W, C = x.shape
+    assert wk.shape == (k * k, C) and wk.is_contiguous() and scale.numel() >= C and shift.numel() >= C
+    return Launch("cp_dwconv2d_nhwc_f32", None, [x, wk, scale, shift, out], [_ld(x), _ld(out), B, H, W, C, k, stride, pad, act])
+
+
+def dwconv2d(x, wk, scale, shift, out, k, stride, pad, act=ACT_NONE):
+    dwconv2d_launch(x, wk, scale, shift, out, k, stride, pad, act).run()
+    return out
+
+
+def global_avgpool_launch(x, out):
+    """x NHWC [B,H,W,C] -> out [B,1,1,C]"""
+    B, H, W, C = x.shape
+    return Launch("cp_global_avgpool_nhwc_f32", None, [x, out], [_ld(x), _ld(out), B, H * W, C])
+
+
+def global_avgpool(x, out):
+    global_avgpool_launch(x, out).run()
+    return out
+
+
+def scale_add_launch(x, se, add, out):
+    """out = x * se[b, c] (+ add); se [B,1,1,C]"""
+    B, H, W, C = x.shape
+    return Launch("cp_scale_add_nhwc_f32", None, [x, se, add, out], [_ld(x), _ld(se), _ld(add) if add is not None else 0, _ld(out), B, H, W, C])
+
+
+def scale_add(x, se, add, out):
+    scale_add_launch(x, se, add, out).run()
+    return out
+
+
+def shuffle_concat_launch(x1, x2, out, h, hp):
+    """channel_shuffle(cat(x1[..., :h], x2[..., :h]), 2) into out's two hp-channel halves (see csrc/elementwise.hip)."""
+    B, H, W, _ = out.shape
+    assert out.shape[3] >= 2 * hp and x1.shape[:3] == out.shape[:3] == x2.shape[:3]
+    return Launch("cp_shuffle_concat_nhwc_f32", None, [x1, x2, out], [_ld(x1), _ld(x2), _ld(out), B * H * W, h, hp])
+
+
+def shuffle_concat(x1, x2, out, h, hp):
+    shuffle_concat_launch(x1, x2, out, h, hp).run()
     return out
 
 

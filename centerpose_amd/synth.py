@@ -35,11 +35,13 @@ def _feeds_residual_add(name):
         if name.endswith(".bn2.weight") and ".layer" in name:
             return False
         return True
+    if ".bneck" in name and (name.endswith(".bn3.weight") or name.endswith(".shortcut.1.weight")):   # MobileNetV3 block output / shortcut
+        return True
     return ".fuse_layers." in name and name.endswith(".1.weight")
 
 
 # empirical damping of the remaining BN gammas so that activations stay O(1) through depth
-GAMMA_DAMP = {"dla_34": 0.8, "res_50": 0.75, "hrnet": 0.62}
+GAMMA_DAMP = {"dla_34": 0.8, "res_50": 0.75, "hrnet": 0.62, "mobilenetv3": 0.8, "shufflenetV2": 0.65}
 
 HEAD_TARGET = {  # final 1x1 layer: (output std, bias)
     "hm": (3.0, -1.0), "wh": (4.0, 12.0), "hps": (8.0, 0.0), "reg": (0.2, 0.5), "hm_hp": (3.0, -1.5),
@@ -80,6 +82,8 @@ def make_state_dict(arch, seed=317, head_conv=None, H=512, W=512):
             v = r.randn(*shp) * (1.5 / math.sqrt(fan * 0.6))
         elif ".up_" in name:
             v = _bilinear_up(shp[0], shp[2]) * r.uniform(0.9, 1.1, (shp[0], 1, 1, 1))
+        elif "deconv_layers" in name and shp[2] == 3:                 # ShuffleNetV2's DCN weights [Co,Ci,3,3] (mask ~ 0.5)
+            v = r.randn(*shp) * (1.7 * math.sqrt(2.0 / (shp[1] * 9)))
         elif "deconv_layers" in name:                                 # ConvTranspose2d [Ci,Co,4,4]
             v = r.randn(*shp) * math.sqrt(2.0 / (shp[0] * 4))
         else:

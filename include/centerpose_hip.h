@@ -23,7 +23,8 @@ const char* cp_target_arch(void);            /* "gfx950" */
 const char* cp_last_error(void);
 const char* cp_last_kernel(void);            /* device kernel (template instantiation) the calling thread launched last */
 
-enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_SIGMOID = 2 };
+enum { CP_ACT_NONE = 0, CP_ACT_RELU = 1, CP_ACT_SIGMOID = 2,
+       CP_ACT_HSWISH = 3, CP_ACT_HSIGMOID = 4 };   /* x*relu6(x+3)/6, relu6(x+3)/6: lib/models/backbones/mobilenet/mobilenetv3.py:87-96 */
 
 /* ---- fused convolution (implicit GEMM, fp32 MFMA) ------------------------------------------------
  * Replaces nn.Conv2d + BatchNorm2d(eval) + ReLU + residual add + torch.cat (+ sigmoid) of
@@ -106,6 +107,19 @@ int cp_dw_deconv_add_nhwc_f32(const float* in, int inLd, const float* w, const f
 /* HRNet fuse: out = relu?( sum_i nearest_upsample(src_i, 2^shift_i) ) (pose_higher_hrnet.py:217-235) */
 int cp_sum_up_nhwc_f32(int n, const float* const* src, const int* ld, const int* shift, float* out, int outLd, int B, int H,
                        int W, int C, int relu, void* stream);
+/* depthwise k x k conv + folded BN + activation (groups == channels): MobileNetV3 Block.conv2 (mobilenetv3.py:119-121, k 3 / 5,
+ * stride 1 / 2) and ShuffleNetV2 banch1 / banch2 (shufflenetv2_dcn.py:67-88); w: [k*k][C], scale / shift: [C] */
+int cp_dwconv2d_nhwc_f32(const float* in, int inLd, const float* w, const float* scale, const float* shift, float* out, int outLd,
+                         int B, int H, int W, int C, int k, int s, int p, int act, void* stream);
+/* SeModule (mobilenetv3.py:99-113): nn.AdaptiveAvgPool2d(1) of in [B,HW,C] -> out [B,C]; then out = x * se[b,c] (+ add:
+ * the block's shortcut, mobilenetv3.py:141-143) */
+int cp_global_avgpool_nhwc_f32(const float* in, int inLd, float* out, int outLd, int B, int HW, int C, void* stream);
+int cp_scale_add_nhwc_f32(const float* x, int xLd, const float* se, int seLd, const float* add, int addLd, float* out, int outLd,
+                          int B, int H, int W, int C, void* stream);
+/* channel_shuffle(torch.cat((x1, x2), 1), 2) of ShuffleNetV2 (shufflenetv2_dcn.py:28-42,94-104); x1, x2: h channels each;
+ * out: two halves of hp (>= h, multiple of 16) physical channels, logical channel c -> c (c < h) or hp + c - h; pads = 0 */
+int cp_shuffle_concat_nhwc_f32(const float* x1, int ld1, const float* x2, int ld2, float* out, int outLd, long long npix, int h, int hp,
+                               void* stream);
 int cp_nchw_to_nhwc_f32(const float* in, float* out, int B, int C, int H, int W, int outLd, int cOff, void* stream);
 int cp_nhwc_to_nchw_f32(const float* in, int inLd, int cOff, float* out, int B, int C, int H, int W, void* stream);
 int cp_fill_f32(float* p, float v, long long n, void* stream);

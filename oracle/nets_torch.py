@@ -15,6 +15,9 @@ Reference lines:
   res_50   : lib/models/backbones/msra_resnet.py   (Bottleneck :64-102, PoseResNet :113-208)
   hrnet_w32: lib/models/backbones/pose_higher_hrnet.py (module :98-235, net :245-503) with
              experiments/hrnet_w32_512.yaml:63-130
+  mobilenetv3 : lib/models/backbones/mobilenet/mobilenetv3.py (Block :116-144, SeModule :99-113, hswish / hsigmoid :87-96,
+             MobileNetV3 :160-222)
+  shufflenetV2: lib/models/backbones/shufflenetv2_dcn.py (channel_shuffle :28-42, InvertedResidual :55-104, ShuffleNetV2 :106-222)
   head     : lib/models/heads/keypoint.py:14-42
 """
 import torch
@@ -81,15 +84,19 @@ def dla34_base(sd, x, p="backbone_model.base"):
     return y
 
 
-def deform_conv(sd, p, x, dcn_impl=None):
-    """DeformConv.forward pose_dla_dcn.py:345-348 + DCN.forward DCNv2/dcn_v2.py:117-127."""
+def dcn_module(sd, p, x, dcn_impl=None):
+    """DCN.forward DCNv2/dcn_v2.py:117-127 (module `p`: weight, bias, conv_offset_mask)."""
     dcn_impl = dcn_impl or _dcn.dcn_v2_forward_torch
-    om = _conv(sd, p + ".conv.conv_offset_mask", x, 1, 1)
+    om = _conv(sd, p + ".conv_offset_mask", x, 1, 1)
     o1, o2, mask = torch.chunk(om, 3, dim=1)
     offset = torch.cat((o1, o2), dim=1)
     mask = torch.sigmoid(mask)
-    out = dcn_impl(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], offset, mask)
-    return F.relu(_bn(sd, p + ".actf.0", out))
+    return dcn_impl(x, sd[p + ".weight"], sd[p + ".bias"], offset, mask)
+
+
+def deform_conv(sd, p, x, dcn_impl=None):
+    """DeformConv.forward pose_dla_dcn.py:345-348."""
+    return F.relu(_bn(sd, p + ".actf.0", dcn_module(sd, p + ".conv", x, dcn_impl)))
 
 
 def _ida_up(sd, p, layers, startp, endp, dcn_impl=None):
@@ -221,6 +228,100 @@ def hrnet_w32_backbone(sd, x, p="backbone_model"):
     return ys[0]
 
 
+# ------------------------------------------------------------------ MobileNetV3 ----------
+def _hswish(x):
+    """mobilenetv3.py:87-90"""
+    return x * F.relu6(x + 3) / 6
+
+
+def _hsigmoid(x):
+    """mobilenetv3.py:93-96"""
+    return F.relu6(x + 3) / 6
+
+
+def _mb_block(sd, p, x, k, cin, cout, act, se, stride):
+    """Block.forward mobilenetv3.py:137-144"""
+    out = act(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
+    w2 = sd[p + ".conv2.weight"]
+    out = act(_bn(sd, p + ".bn2", F.conv2d(out, w2, None, stride, k // 2, 1, w2.shape[0])))
+    out = _bn(sd, p + ".bn3", _conv(sd, p + ".conv3", out))
+    if se:                                              # SeModule.forward :112-113
+        g = F.adaptive_avg_pool2d(out, 1)
+        g = F.relu(_bn(sd, p + ".se.se.2", _conv(sd, p + ".se.se.1", g)))
+        g = _hsigmoid(_bn(sd, p + ".se.se.5", _conv(sd, p + ".se.se.4", g)))
+        out = out * g
+    if stride == 1:
+        sc = x if cin == cout else _bn(sd, p + ".shortcut.1", _conv(sd, p + ".shortcut.0", x))
+        out = out + sc
+    return out
+
+
+MBV3 = [[(3, 16, 16, 16, F.relu, 0, 1), (3, 16, 64, 24, F.relu, 0, 2), (3, 24, 72, 24, F.relu, 0, 1)],
+        [(5, 24, 72, 40, F.relu, 1, 2), (5, 40, 120, 40, F.relu, 1, 1), (5, 40, 120, 40, F.relu, 1, 1)],
+        [(3, 40, 240, 80, _hswish, 0, 2), (3, 80, 200, 80, _hswish, 0, 1), (3, 80, 184, 80, _hswish, 0, 1), (3, 80, 184, 80, _hswish, 0, 1),
+         (3, 80, 480, 112, _hswish, 1, 1), (3, 112, 672, 112, _hswish, 1, 1), (5, 112, 672, 160, _hswish, 1, 1)],
+        [(5, 160, 672, 160, _hswish, 1, 2), (5, 160, 960, 160, _hswish, 1, 1)]]          # mobilenetv3.py:167-188
+
+
+def mobilenetv3_backbone(sd, x, dcn_impl=None, p="backbone_model"):
+    """MobileNetV3.forward mobilenetv3.py:209-222"""
+    out = _hswish(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, 2, 1)))
+    outs = []
+    for si, blocks in enumerate(MBV3):
+        for bi, (k, ci, ce, co, act, se, st) in enumerate(blocks):
+            out = _mb_block(sd, "%s.bneck%d.%d" % (p, si, bi), out, k, ci, co, act, se, st)
+        outs.append(out)
+    outs[3] = _hswish(_bn(sd, p + ".bn2", _conv(sd, p + ".conv2", outs[3])))
+    y = [o.clone() for o in outs]
+    _ida_up(sd, p + ".ida_up", y, 0, len(y), dcn_impl)
+    return y[-1]
+
+
+# ------------------------------------------------------------------ ShuffleNetV2 ---------
+def _channel_shuffle(x, groups):
+    """shufflenetv2_dcn.py:28-42"""
+    b, c, h, w = x.shape
+    return x.view(b, groups, c // groups, h, w).transpose(1, 2).contiguous().view(b, -1, h, w)
+
+
+def _dw(sd, p, x, stride):
+    w = sd[p + ".weight"]
+    return F.conv2d(x, w, None, stride, 1, 1, w.shape[0])
+
+
+def _shuffle_block(sd, p, x, stride, benchmodel):
+    """InvertedResidual.forward shufflenetv2_dcn.py:94-104"""
+    def banch2(t):
+        t = F.relu(_bn(sd, p + ".banch2.1", _conv(sd, p + ".banch2.0", t)))
+        t = _bn(sd, p + ".banch2.4", _dw(sd, p + ".banch2.3", t, stride))
+        return F.relu(_bn(sd, p + ".banch2.6", _conv(sd, p + ".banch2.5", t)))
+    if benchmodel == 1:
+        h = x.shape[1] // 2
+        out = torch.cat((x[:, :h], banch2(x[:, h:])), 1)
+    else:
+        b1 = _bn(sd, p + ".banch1.1", _dw(sd, p + ".banch1.0", x, stride))
+        b1 = F.relu(_bn(sd, p + ".banch1.3", _conv(sd, p + ".banch1.2", b1)))
+        out = torch.cat((b1, banch2(x)), 1)
+    return _channel_shuffle(out, 2)
+
+
+def shufflenetv2_backbone(sd, x, dcn_impl=None, p="backbone_model"):
+    """ShuffleNetV2.forward shufflenetv2_dcn.py:214-220 (width 1.0: stages 116 / 232 / 464, repeats 4 / 8 / 4)."""
+    x = F.relu(_bn(sd, p + ".conv1.1", _conv(sd, p + ".conv1.0", x, 2, 1)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    i = 0
+    for rep in (4, 8, 4):
+        for j in range(rep):
+            x = _shuffle_block(sd, "%s.features.%d" % (p, i), x, 2 if j == 0 else 1, 2 if j == 0 else 1)
+            i += 1
+    for d in range(3):                                  # _make_deconv_layer :172-206: DCN, BN, ReLU, ConvT k4 s2 p1, BN, ReLU
+        q = "%s.deconv_layers." % p
+        x = F.relu(_bn(sd, q + str(6 * d + 1), dcn_module(sd, q + str(6 * d), x, dcn_impl)))
+        x = F.conv_transpose2d(x, sd[q + str(6 * d + 3) + ".weight"], None, 2, 1)
+        x = F.relu(_bn(sd, q + str(6 * d + 4), x))
+    return x
+
+
 # ------------------------------------------------------------------ head + full model ----
 HEADS = ("hm", "wh", "hps", "reg", "hm_hp", "hp_offset")
 
@@ -238,11 +339,14 @@ BACKBONES = {"dla_34": dla34_backbone, "res_50": res50_backbone, "hrnet": hrnet_
              "hrnet_32": hrnet_w32_backbone}
 
 
+DCN_BACKBONES = {"dla_34": dla34_backbone, "mobilenetv3": mobilenetv3_backbone, "shufflenetV2": shufflenetv2_backbone}
+
+
 def forward(arch, sd, images, dcn_impl=None):
     """BackBoneWithHead.forward lib/models/model.py:57-59."""
     with torch.no_grad():
-        if arch == "dla_34":
-            feat = dla34_backbone(sd, images, dcn_impl)
+        if arch in DCN_BACKBONES:
+            feat = DCN_BACKBONES[arch](sd, images, dcn_impl)
         else:
             feat = BACKBONES[arch](sd, images)
         return keypoint_head(sd, feat)

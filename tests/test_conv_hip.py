@@ -169,6 +169,70 @@ def test_sum_up():
     _close(out.permute(0, 3, 1, 2), ref, 1e-6)
 
 
+@pytest.mark.parametrize("C,k,stride,act", [(16, 3, 1, 0), (72, 5, 2, 1), (64, 3, 2, 3), (240, 5, 1, 3), (24, 3, 1, 4)])
+def test_dwconv_bn_act(C, k, stride, act):
+    """depthwise k x k + folded BN + {none, relu, h-swish, h-sigmoid} vs torch (mobilenetv3.py:119-121, shufflenetv2_dcn.py:67-88)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(C + k)
+    B, H, W = 2, 13, 18
+    x = torch.randn(B, C, H, W, generator=g) * 2
+    w = torch.randn(C, 1, k, k, generator=g) * 0.3
+    bn = _rand_bn(g, C)
+    ref = _ref_bn(F.conv2d(x, w, None, stride, k // 2, 1, C), bn)
+    ref = {0: ref, 1: F.relu(ref), 3: ref * F.relu6(ref + 3) / 6, 4: F.relu6(ref + 3) / 6}[act]
+    Cp = (C + 15) // 16 * 16
+    xp = torch.zeros(B, H, W, Cp)
+    xp[..., :C] = x.permute(0, 2, 3, 1)
+    gm, bt, mean, var = bn
+    scale = gm / torch.sqrt(var + 1e-5)
+    pad = lambda v: torch.cat([v, torch.zeros(Cp - C)]).cuda()
+    wk = torch.cat([ops.pack_dw_weight(w), torch.zeros(k * k, Cp - C)], 1).contiguous().cuda()
+    Ho, Wo = ref.shape[2:]
+    out = torch.full((B, Ho, Wo, Cp), float("nan"), device="cuda")
+    ops.dwconv2d(xp.cuda(), wk, pad(scale), pad(bt - mean * scale), out, k, stride, k // 2, act)
+    _close(out[..., :C].permute(0, 3, 1, 2), ref, 1e-5)
+    if act != 4:
+        assert torch.equal(out[..., C:], torch.zeros_like(out[..., C:]))     # padding channels stay exact zeros
+
+
+def test_squeeze_excite_pieces():
+    """global average pool and x * se (+ shortcut) vs torch (SeModule, mobilenetv3.py:99-113,141-143)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 11, 7, 48, generator=g).cuda()
+    sc = torch.randn(3, 11, 7, 48, generator=g).cuda()
+    pooled = torch.empty(3, 1, 1, 48, device="cuda")
+    ops.global_avgpool(x, pooled)
+    _close(pooled, x.mean((1, 2), keepdim=True), 1e-6)
+    se = torch.rand(3, 1, 1, 48, generator=g).cuda()
+    out = torch.empty_like(x)
+    ops.scale_add(x, se, sc, out)
+    assert torch.equal(out, x * se + sc)
+    ops.scale_add(x, se, None, out)
+    assert torch.equal(out, x * se)
+
+
+@pytest.mark.parametrize("h", [58, 116, 16, 29])
+def test_channel_shuffle_concat(h):
+    """channel_shuffle(cat(x1, x2), 2) (shufflenetv2_dcn.py:28-42) into the split layout; the halves come back as views."""
+    from centerpose_amd import ops
+    hp = (h + 15) // 16 * 16
+    g = torch.Generator().manual_seed(h)
+    x1, x2 = torch.randn(2, h, 5, 6, generator=g), torch.randn(2, h, 5, 6, generator=g)
+    cat = torch.cat((x1, x2), 1)
+    ref = cat.view(2, 2, h, 5, 6).transpose(1, 2).contiguous().view(2, 2 * h, 5, 6)
+    a = torch.zeros(2, 5, 6, 2 * hp)
+    a[..., :h] = x1.permute(0, 2, 3, 1)                   # x1 arrives as a half-view of a wider tensor (ld = 2 hp)
+    b = torch.zeros(2, 5, 6, hp)
+    b[..., :h] = x2.permute(0, 2, 3, 1)
+    ad = a.cuda()
+    out = torch.full((2, 5, 6, 2 * hp), float("nan"), device="cuda")
+    ops.shuffle_concat(ad[..., :hp], b.cuda(), out, h, hp)
+    o = out.cpu()
+    assert torch.equal(o[..., :h].permute(0, 3, 1, 2), ref[:, :h]) and torch.equal(o[..., hp:hp + h].permute(0, 3, 1, 2), ref[:, h:])
+    assert torch.equal(o[..., h:hp], torch.zeros(2, 5, 6, hp - h)) and torch.equal(o[..., hp + h:], torch.zeros(2, 5, 6, hp - h))
+
+
 def _dcn_case(seed, B, C, Co, H, W, big_offsets):
     r = np.random.RandomState(seed)
     x = r.randn(B, C, H, W).astype(np.float32)

@@ -13,7 +13,7 @@ import torch
 from oracle import decode_np, nets_torch
 
 pytestmark = pytest.mark.gpu
-ARCHS = ["dla_34", "res_50", "hrnet"]
+ARCHS = ["dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2"]
 
 
 def _check_heads(outs, refs):
@@ -38,7 +38,8 @@ def test_forward_matches_reference_golden(arch, golden_dir):
     _check_heads(outs, refs)
 
 
-@pytest.mark.parametrize("arch,B,hw", [("dla_34", 3, (160, 96)), ("res_50", 2, (96, 160)), ("hrnet", 2, (64, 128))])
+@pytest.mark.parametrize("arch,B,hw", [("dla_34", 3, (160, 96)), ("res_50", 2, (96, 160)), ("hrnet", 2, (64, 128)),
+                                       ("mobilenetv3", 2, (96, 160)), ("shufflenetV2", 3, (160, 96))])
 def test_forward_matches_oracle_ragged_shapes(arch, B, hw):
     """non-square inputs, batch > 1, hipGraph replay (twice: static buffers must be reusable)."""
     from centerpose_amd import engine, synth
@@ -173,7 +174,7 @@ print("child ok", p.n_launches)
 """
 
 
-@pytest.mark.parametrize("arch", ["dla_34", "hrnet"])
+@pytest.mark.parametrize("arch", ["dla_34", "hrnet", "mobilenetv3", "shufflenetV2"])
 def test_c_plan_handle_runs_network_without_engine(arch, tmp_path):
     """cp_plan_load / cp_plan_forward / cp_plan_process / cp_plan_destroy.  A fresh interpreter that imports
     neither engine.py nor ops.py runs the plan file through the C ABI alone; heads and dets equal the Python engine's bits."""

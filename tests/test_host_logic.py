@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_param_spec_counts_and_flops():
     from centerpose_amd import nets
-    for arch, nkeys, gf in (("dla_34", 410, 80.34), ("res_50", 360, 86.85), ("hrnet", 1776, 85.27)):
+    for arch, nkeys, gf in (("dla_34", 410, 80.34), ("res_50", 360, 86.85), ("hrnet", 1776, 85.27), ("mobilenetv3", 471, 15.59),
+                            ("shufflenetV2", 399, 136.27)):
         spec, flops = nets.param_spec(arch)
         assert len(spec) == nkeys                      # 410 / 360 entries (probe of the reference)
         assert abs(flops / 1e9 - gf) < 0.05
@@ -28,7 +29,7 @@ def test_synth_is_deterministic_and_complete():
 
 
 @pytest.mark.reference
-@pytest.mark.parametrize("arch", ["dla_34", "res_50", "hrnet"])
+@pytest.mark.parametrize("arch", ["dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2"])
 def test_spec_and_oracle_match_imported_reference(arch):
     """key names/shapes == the reference module's state_dict; torch oracle == reference forward."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -53,7 +54,7 @@ def test_spec_and_oracle_match_imported_reference(arch):
 def test_oracle_matches_reference_golden_nets(golden_dir):
     from centerpose_amd import synth
     from oracle import nets_torch
-    for arch in ("dla_34", "res_50", "hrnet"):
+    for arch in ("dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2"):
         g = np.load(os.path.join(golden_dir, "net_%s_128.npz" % arch))
         out = nets_torch.forward(arch, synth.make_state_dict(arch), synth.make_images(1, 128, 128, seed=7))
         for i, o in enumerate(out):

@@ -102,7 +102,8 @@ def test_post_process_hand_computed():
 def test_arch_presets_equal_the_reference_yamls():
     import yaml
     from centerpose_amd import config
-    for arch, f in (("dla_34", "dla_34_512x512.yaml"), ("res_50", "res_50_512x512.yaml"), ("hrnet", "hrnet_w32_512.yaml")):
+    for arch, f in (("dla_34", "dla_34_512x512.yaml"), ("res_50", "res_50_512x512.yaml"), ("hrnet", "hrnet_w32_512.yaml"),
+                    ("mobilenetv3", "mobilenetv3_512x512.yaml"), ("shufflenetV2", "shufflenetV2_512x512.yaml")):
         y = yaml.safe_load(open(os.path.join("/root/reference/experiments", f)))
         cfg = config.get_cfg(arch)
         for k in ("FLIP_TEST", "NMS", "FIX_RES", "TEST_SCALES", "TOPK"):
