@@ -44,7 +44,12 @@ __device__ __forceinline__ float key2f(uint32_t k)
 // ------------------------------------------------------------------------------------------
 // K6: NMS + top-K of one plane group (centre: cat planes of H*W flattened; joints: one plane)
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(TK_THREADS) void nms_topk_kernel(
+// CHUNKED = false is the LDS-resident case (the 128 x 128 maps of the 512 x 512 configurations): one pass, the chunk loop and
+// its extra barrier compile away.  __launch_bounds__(1024, 8): TWO 16-wave blocks per CU (8 waves per SIMD) need <= 64 VGPRs
+// AND <= 80 SGPRs per wave; at 91 SGPRs only seven waves per SIMD are admitted, i.e. one block per CU, and the 288 blocks of
+// a 16-image batch take two rounds on 256 CUs (157 us instead of 99 us, rocprofv3).
+template <bool CHUNKED>
+__global__ __launch_bounds__(TK_THREADS, 8) void nms_topk_kernel(
     const float* __restrict__ heat, const float* __restrict__ hm_hp, int cat, int J, int H, int W,
     int K, int P /* pow2 >= K */, int nmax /* LDS key slots, multiple of 4 */, int chunk /* keys per pass through LDS, <= nmax */,
     float* __restrict__ out_scores, int* __restrict__ out_inds)
@@ -66,11 +71,11 @@ __global__ __launch_bounds__(TK_THREADS) void nms_topk_kernel(
     uint32_t* sctl = wsum + TK_WAVES;                                      // [4] digit, remaining, cnt_gt
 
     const int ntot = n;
-    for (int c0 = 0; c0 < ntot; c0 += chunk) {
+    for (int c0 = 0; c0 < (CHUNKED ? ntot : 1); c0 += chunk) {
     // keys of flat indices [c0, c0 + n) live in LDS; candidates carry the global index c0 + e
-    n = min(chunk, ntot - c0);
-    unsigned long long* cand = c0 == 0 ? cand0 : cand0 + P;
-    __syncthreads();      // previous chunk's merge has finished with keys / cand
+    if (CHUNKED) n = min(chunk, ntot - c0);
+    unsigned long long* cand = (!CHUNKED || c0 == 0) ? cand0 : cand0 + P;
+    if (CHUNKED) __syncthreads();      // previous chunk's merge has finished with keys / cand
     // ---- phase 1: 3x3 NMS (decode.py:10-16; -inf padding == skip out-of-range) -> keys
     for (int e = tid; e < n; e += TK_THREADS) {
         const int c = (c0 + e) / HW, p = (c0 + e) - c * HW;
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(TK_THREADS) void nms_topk_kernel(
 
     // ---- phase 4: bitonic sort, descending (value desc, index asc): the first chunk's P candidates, afterwards the
     // running top-P together with this chunk's P candidates (the better half stays in cand0[0, P))
-    const int S = c0 == 0 ? P : 2 * P;
+    const int S = (!CHUNKED || c0 == 0) ? P : 2 * P;
     for (int k2 = 2; k2 <= S; k2 <<= 1) {
         for (int j = k2 >> 1; j > 0; j >>= 1) {
             for (int i = tid; i < S; i += TK_THREADS) {
@@ -293,15 +298,19 @@ extern "C" int cp_multi_pose_decode_f32(const float* heat, const float* wh, cons
     const int chunk = (cp_cdiv(nbig, nchunks) + 3) & ~3;
     const int nmax = chunk;
     const size_t lds = (size_t)nmax * 4 + 2 * TK_MAX_K * 8 + 256 * 4 + TK_WAVES * 4 + 16;
-    static size_t lds_reserved = 0;   // one device per process (one rank per GPU)
-    if (lds > lds_reserved) {
-        hipError_t e = hipFuncSetAttribute((const void*)nms_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static size_t lds_reserved[2] = {0, 0};   // one device per process (one rank per GPU)
+    const int ck = nchunks > 1;
+    if (lds > lds_reserved[ck]) {
+        hipError_t e = hipFuncSetAttribute(ck ? (const void*)nms_topk_kernel<true> : (const void*)nms_topk_kernel<false>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cp_set_error("decode: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return 2; }
-        lds_reserved = lds;
+        lds_reserved[ck] = lds;
     }
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(nms_topk_kernel, dim3(B * (1 + J)), dim3(TK_THREADS), lds, s, heat, hm_hp, cat, J, H, W, K, P,
-                       nmax, chunk, ws_scores, ws_inds);
+    if (ck) hipLaunchKernelGGL(nms_topk_kernel<true>, dim3(B * (1 + J)), dim3(TK_THREADS), lds, s, heat, hm_hp, cat, J, H, W, K, P,
+                               nmax, chunk, ws_scores, ws_inds);
+    else hipLaunchKernelGGL(nms_topk_kernel<false>, dim3(B * (1 + J)), dim3(TK_THREADS), lds, s, heat, hm_hp, cat, J, H, W, K, P,
+                            nmax, chunk, ws_scores, ws_inds);
     CP_CHECK_LAUNCH("nms_topk_kernel");
     hipLaunchKernelGGL(pose_assign_kernel, dim3(B * J), dim3(128), 0, s, wh, kps, reg, hp_offset, ws_scores, ws_inds, J,
                        H, W, K, dets);

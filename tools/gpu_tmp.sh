@@ -1,3 +1,4 @@
 #!/bin/bash
-for sd in 0.3 1.0 1.5 3 6; do echo "om std $sd"; CP_OM_STD=$sd timeout 120 python tools/bench_conv.py d64_128,d128_64,d512_16 0; done
-timeout 200 python tools/om_stats.py dla_34
+timeout 300 python -m pytest tests/test_decode_hip.py -m gpu -q -x 2>&1 | tail -2
+timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; l=json.loads(sys.stdin.read()); print(l['value'], l['ms_per_step'], l['decode'])"
