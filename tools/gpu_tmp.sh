@@ -1,13 +1,4 @@
 #!/bin/bash
-OUT=gpurun_out/r2i; mkdir -p $OUT
-tools/gpu_profile.sh r2i pmc > $OUT/profile.log 2>&1
-timeout 200 python tools/layer_profile.py res_50 16 > $OUT/layers_res50.txt 2>&1
-timeout 200 python tools/layer_profile.py hrnet 16 > $OUT/layers_hrnet.txt 2>&1
-timeout 300 python bench.py > $OUT/bench_default.json 2>/dev/null
-for cfg in "res_50 8" "res_50 16" "hrnet 8" "hrnet 16" "mobilenetv3 16" "shufflenetV2 16"; do set -- $cfg
-  timeout 200 python bench.py --arch $1 --batch $2 --no-cpu-baseline 2>/dev/null > $OUT/bench_$1_$2.json
-  python -c "
-import json; l=json.load(open('$OUT/bench_$1_$2.json')); r=l['roofline']; print('$1 B=$2', l['value'], 'img/s', l['ms_per_step'], 'ms; dom', r['kernel'][:40], r['frac'], 'all-mfma exe frac', r['all_mfma_kernels']['executed_frac'], 'act MB', l['activation_mb'])"
-done
-python -c "
-import json; l=json.load(open('$OUT/bench_default.json')); print(l['value'], l['ms_per_step'], l['roofline']['kernel'], l['roofline']['frac'], l['roofline']['traffic'], l['cpu_baseline']['value'])"
+for d in 0 3 2; do echo "CP_DCN_DEBUG=$d"; CP_DCN_DEBUG=$d timeout 120 python tools/bench_conv.py d64_128,d128_64,d512_16 0; done
+for d in 0 3 2; do CP_DCN_DEBUG=$d timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; l=json.loads(sys.stdin.read()); k=[v for n,v in l['roofline']['kernels'].items() if n.startswith('dcn')][0]; print('debug $d', l['value'], 'dcn ms', k['ms_per_step'], k['executed_tflops'])"; done
