@@ -62,21 +62,22 @@ __device__ __forceinline__ wg_v4 wg_lds4(const float* p) { return *reinterpret_c
 __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, const f32x16 (&acc)[4], int xi, int h, int m, int tid,
                                                int b, int yb, int x0, int tile, bool store)
 {
+    const float* const a_res = a.res;
     const bool relu = a.act == CP_ACT_RELU, sigm = a.act == CP_ACT_SIGMOID;
     const bool vec_ok = (a.outLd & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
-                        (!a.res || ((a.resLd & 3) == 0 && (((size_t)a.res) & 15) == 0));
+                        (!a_res || ((a.resLd & 3) == 0 && (((size_t)a_res) & 15) == 0));
     // The MFMA is issued as D[channel][tile] (A = U fragment, B = V fragment), so a lane holds 4 x 4 consecutive
     // channels (8j + 4h .. +3) of tile m: the reduction buffer red[(xi*2+bcol)*32 + tile][channel] is written with
     // ds_write_b128 (pitch 36 floats: the 16 tiles of a b128 lane group land on 16 distinct 4-bank groups).
     float* wp = red + (xi * 64 + m) * WG_LDR + 4 * h;
-    {
-        const f32x16 s0 = acc[0] + acc[1] + acc[2];
-        const f32x16 s1 = acc[1] - acc[2] - acc[3];
+    // four accumulator elements at a time (no 2 x 16-register temporaries next to the 64 accumulator and 128 V registers)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<wg_v4*>(wp + 8 * j) = (wg_v4){s0[4 * j], s0[4 * j + 1], s0[4 * j + 2], s0[4 * j + 3]};
-            *reinterpret_cast<wg_v4*>(wp + 32 * WG_LDR + 8 * j) = (wg_v4){s1[4 * j], s1[4 * j + 1], s1[4 * j + 2], s1[4 * j + 3]};
-        }
+    for (int j = 0; j < 4; ++j) {
+        wg_v4 q[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) q[nu] = (wg_v4){acc[nu][4 * j], acc[nu][4 * j + 1], acc[nu][4 * j + 2], acc[nu][4 * j + 3]};
+        *reinterpret_cast<wg_v4*>(wp + 8 * j) = (q[0] + q[1]) + q[2];
+        *reinterpret_cast<wg_v4*>(wp + 32 * WG_LDR + 8 * j) = (q[1] - q[2]) - q[3];
     }
     // per-thread output items (tile mi, column bb, 4 channels n4); their scale / shift / residual loads are issued
     // BEFORE the barrier so that the global-memory latency overlaps the cross-wave hand-over
@@ -98,9 +99,9 @@ __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, co
         if (itvec[it]) {
             sc[it] = *reinterpret_cast<const wg_v4*>(a.scale + itn[it]);
             sh[it] = *reinterpret_cast<const wg_v4*>(a.shift + itn[it]);
-            if (a.res) {
-                rr[it][0] = *reinterpret_cast<const wg_v4*>(a.res + itpix[it] * a.resLd + itn[it]);
-                if (itoy[it] + 1 < a.H) rr[it][1] = *reinterpret_cast<const wg_v4*>(a.res + (itpix[it] + a.W) * a.resLd + itn[it]);
+            if (a_res) {
+                rr[it][0] = *reinterpret_cast<const wg_v4*>(a_res + itpix[it] * a.resLd + itn[it]);
+                if (itoy[it] + 1 < a.H) rr[it][1] = *reinterpret_cast<const wg_v4*>(a_res + (itpix[it] + a.W) * a.resLd + itn[it]);
             }
         }
     }
@@ -120,7 +121,7 @@ __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, co
                 if (itoy[it] + aa >= a.H) continue;
                 const size_t opix = itpix[it] + (size_t)aa * a.W;
                 wg_v4 v = __builtin_elementwise_fma(yv[aa], sc[it], sh[it]);
-                if (a.res) v += rr[it][aa];
+                if (a_res) v += rr[it][aa];
                 if (relu) v = __builtin_elementwise_max(v, (wg_v4){0.f, 0.f, 0.f, 0.f});
                 else if (sigm) {
                     v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
@@ -137,7 +138,7 @@ __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, co
                 for (int k = 0; k < 4; ++k) {
                     if (n + k >= a.Cout) break;
                     float w_ = yv[aa][k] * a.scale[n + k] + a.shift[n + k];
-                    if (a.res) w_ += a.res[opix * a.resLd + n + k];
+                    if (a_res) w_ += a_res[opix * a.resLd + n + k];
                     w_ = cp_act(w_, a.act);
                     a.out[opix * a.outLd + n + k] = w_;
                 }
@@ -544,8 +545,8 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
     const int ntiles = (a.Cout + 31) / 32;
     // variant = MT*10 + NT (tuning / tests); 0 = auto.  Measured on MI355X (tools/bench_conv.py, B = 16): the 8x16-pixel x
     // 64-channel block (NT = 2: every V fragment feeds two MFMAs) is the best general shape on every DLA-34 / ResNet-50
-    // layer; a single 32-channel tile (DCN offset convs) takes the 32-channel block.  The larger shapes (21, 22, 41)
-    // stay selectable: they were ahead before the global loads moved inside the MFMA blocks.
+    // layer; a single 32-channel tile (DCN offset convs) takes the 32-channel block.  (21 stays selectable for tests; the 512-VGPR
+    // one-wave-per-SIMD shapes 22 / 41 measured 10-40 % slower and are no longer instantiated.)
     if (variant == 0) {
         const long long blocks_vs = (long long)a.B * cp_cdiv(a.H, 8) * cp_cdiv(a.W, WG_TW);
         // 64 input channels and >= 4 channel tiles (the head convs): V-stationary kernel, one block per spatial tile
@@ -558,8 +559,6 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
         case 11: return launch_wino<1, 1, 16, 2>(a, s);
         case 12: return launch_wino<1, 2, 16, 2>(a, s);
         case 21: return launch_wino<2, 1, 16, 2>(a, s);
-        case 41: return launch_wino<4, 1, 16, 2>(a, s);
-        case 22: return launch_wino<2, 2, 16, 2>(a, s);
         default: cp_set_error("conv3x3_winograd: unknown variant %d", variant); return 1;
     }
 }

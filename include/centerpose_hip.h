@@ -66,7 +66,8 @@ int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w
  * cp_winograd_pack_f32: packed direct weights w [rows >= Cout][9*C] (k = (ky*3+kx)*C + c, as for cp_conv2d_f32)
  *   -> u [cp_winograd_weight_floats(C, Cout)] = G g G^T in the kernel's MFMA B-fragment order; C % 16 == 0.
  * cp_conv3x3_winograd_f32: d as for cp_conv2d_f32 with nsrc = 1, kh = kw = 3, stride 1, pad 1, NHWC in/out
- *   (returns 1 for any other shape); d->tile: 0 = auto, MT*10+NT in {11, 12, 21} forces a block shape. */
+ *   (returns 1 for any other shape); d->tile: 0 = auto, MT*10+NT in {11, 12, 21} forces a block shape, 64xx the
+ *   V-stationary kernel for 64 input channels with xx channel-tile groups per spatial tile. */
 size_t cp_winograd_weight_floats(int C, int Cout);
 int cp_winograd_pack_f32(const float* w, float* u, int C, int Cout, void* stream);
 int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,

@@ -335,8 +335,7 @@ def test_conv3x3_patch_kernel(cin, cout, hw, B):
                                               (48, 128, (9, 35), 2, 12), (48, 128, (9, 35), 2, 21), (128, 192, (16, 16), 2, 0),
                                               (64, 256, (32, 32), 1, 21), (256, 96, (8, 8), 2, 11),
                                               (64, 256, (20, 28), 2, 6401), (64, 256, (9, 35), 1, 6403), (64, 64, (16, 16), 2, 6402),
-                                              (64, 27, (19, 16), 2, 6400), (64, 96, (8, 8), 2, 6408),
-                                              (48, 128, (37, 35), 2, 41), (64, 64, (20, 28), 3, 22)])
+                                              (64, 27, (19, 16), 2, 6400), (64, 96, (8, 8), 2, 6408)])
 def test_conv3x3_winograd_kernel(cin, cout, hw, B, nt):
     """fused Winograd F(2x2,3x3) kernel: odd sizes, ragged tiles, residual, ragged channel tiles, scalar-store tail;
     against the torch-CPU fp32 direct convolution.  Tolerance 2e-4 * max|ref| like the direct kernels (measured
@@ -370,7 +369,7 @@ def test_conv3x3_winograd_fuzz_vs_direct_kernel():
     from centerpose_amd import ops
     rng = np.random.RandomState(5)
     g = torch.Generator().manual_seed(5)
-    variants = [0, 11, 12, 21, 22, 41]
+    variants = [0, 11, 12, 21]
     for it in range(14):
         B = int(rng.randint(1, 4))
         H, W = int(rng.randint(3, 41)), int(rng.randint(3, 45))
