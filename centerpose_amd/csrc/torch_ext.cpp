@@ -1,0 +1,167 @@
+// pybind module `_ext`: the reference's only native FFI, re-made for MI355X (SURVEY.md 8b "what the replacement must export").
+//
+//   lib/models/backbones/DCNv2/src/vision.cpp:4-9 exports dcn_v2_forward / dcn_v2_backward from a torch cpp_extension and
+//   DCNv2/dcn_v2.py:12 imports it as `import _ext as _backend`.  This file is that module, built with
+//   torch.utils.cpp_extension (csrc/setup_ext.py) on top of the C ABI of libcenterpose_hip.so:
+//     dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group) -> Tensor
+//         identical 14-argument signature (src/dcn_v2.h:9-23); fp32 contiguous NCHW HIP tensors in, a NEW NCHW tensor out
+//         (at::empty, dcn_v2_cuda.cu:91); CPU tensors raise like AT_ERROR("Not implemented on the CPU") (cpu/dcn_v2_cpu.cpp:7-24)
+//     multi_pose_decode(heat, wh, kps, reg?, hm_hp?, hp_offset?, K) -> Tensor[B,K,5+3J]        (lib/models/decode.py:235-308)
+//     plan_create(path, use_graph) -> handle; plan_forward(handle, images) -> 6 tensors; plan_process(handle, images, K) -> dets;
+//     plan_destroy(handle)                                                                      (lib/models/model.py:57-59)
+// Kernels are enqueued on the current HIP stream of the input's device; nothing synchronises the host.
+#include <torch/extension.h>
+#include <c10/hip/HIPStream.h>
+
+#include "../../include/centerpose_hip.h"
+
+namespace {
+
+void* cur_stream(const at::Tensor& t) { return (void*)c10::hip::getCurrentHIPStream(t.get_device()).stream(); }
+
+void check_gpu_f32(const at::Tensor& t, const char* name)
+{
+    TORCH_CHECK(t.is_cuda(), name, " tensor has to be on GPU (there is no CPU implementation, as in the reference: cpu/dcn_v2_cpu.cpp)");
+    TORCH_CHECK(t.scalar_type() == at::kFloat, name, " must be float32");
+}
+
+#define CP_CALL(expr, what) TORCH_CHECK((expr) == 0, what, ": ", cp_last_error())
+
+at::Tensor nhwc_from_nchw(const at::Tensor& x, int Cpad, int c_off, at::Tensor out)
+{
+    const auto xc = x.contiguous();
+    CP_CALL(cp_nchw_to_nhwc_f32(xc.data_ptr<float>(), out.data_ptr<float>(), (int)xc.size(0), (int)xc.size(1), (int)xc.size(2),
+                                (int)xc.size(3), Cpad, c_off, cur_stream(x)), "cp_nchw_to_nhwc_f32");
+    return out;
+}
+
+at::Tensor dcn_v2_forward(const at::Tensor& input, const at::Tensor& weight, const at::Tensor& bias, const at::Tensor& offset,
+                          const at::Tensor& mask, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
+                          int dilation_h, int dilation_w, int deformable_group)
+{
+    check_gpu_f32(input, "input"); check_gpu_f32(weight, "weight"); check_gpu_f32(bias, "bias");
+    check_gpu_f32(offset, "offset"); check_gpu_f32(mask, "mask");                                   // dcn_v2_cuda.cu:60-64
+    const int B = input.size(0), C = input.size(1), H = input.size(2), W = input.size(3);
+    const int Co = weight.size(0);
+    TORCH_CHECK(weight.size(1) == C, "Input shape and kernel channels wont match: (", C, " vs ", weight.size(1), ").");   // :80-81
+    TORCH_CHECK(weight.size(2) == kernel_h && weight.size(3) == kernel_w, "Input shape and kernel shape wont match: (", kernel_h,
+                " x ", kernel_w, " vs ", weight.size(2), " x ", weight.size(3), ").");                                   // :77-78
+    TORCH_CHECK(stride_h == stride_w && pad_h == pad_w && dilation_h == dilation_w, "square stride / pad / dilation only");
+    TORCH_CHECK(deformable_group == 1, "deformable_group != 1 is not supported (the reference only uses 1, pose_dla_dcn.py:343)");
+    const int kk = kernel_h * kernel_w;
+    TORCH_CHECK(kk <= 9, "at most 9 taps");
+    const int Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) / stride_h + 1;
+    const int Wo = (W + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) / stride_w + 1;
+    TORCH_CHECK(offset.size(0) == B && offset.size(1) == 2 * kk && offset.size(2) == Ho && offset.size(3) == Wo &&
+                mask.size(0) == B && mask.size(1) == kk && mask.size(2) == Ho && mask.size(3) == Wo, "offset / mask shape");
+    const auto opt = input.options();
+    const int Cp = (C + 15) / 16 * 16, omld = (3 * kk + 3) / 4 * 4, Cop = Co > 17 ? Co : 17;
+    // NHWC staging (the fused network plan keeps NHWC end to end; this entry exists so that the reference's own DCN module runs)
+    at::Tensor x = nhwc_from_nchw(input, Cp, 0, Cp != C ? at::zeros({B, H, W, Cp}, opt) : at::empty({B, H, W, Cp}, opt));
+    at::Tensor om = at::zeros({B, Ho, Wo, omld}, opt);
+    nhwc_from_nchw(offset, omld, 0, om);
+    nhwc_from_nchw(mask, omld, 2 * kk, om);
+    // packed weights [ldw][kh*kw*Cp], k = (ky*kw + kx)*Cp + c; ldw = Cout padded to the kernel's N tile; bias as `shift`, scale 1
+    const int ldw = Cop <= 32 ? 32 : (Cop + 63) / 64 * 64;
+    at::Tensor wp = at::zeros({ldw, kk * Cp}, opt);
+    wp.view({ldw, kk, Cp}).slice(0, 0, Co).slice(2, 0, C).copy_(weight.permute({0, 2, 3, 1}).reshape({Co, kk, C}));
+    at::Tensor scale = at::zeros({ldw}, opt), shift = at::zeros({ldw}, opt);
+    scale.slice(0, 0, Co).fill_(1.0f);
+    shift.slice(0, 0, Co).copy_(bias);
+    at::Tensor out = at::empty({B, Co, Ho, Wo}, opt);                                               // new tensor, dcn_v2_cuda.cu:91
+    cp_dcn_desc d = {};
+    d.B = B; d.H = H; d.W = W; d.C = Cp; d.srcLd = Cp; d.Ho = Ho; d.Wo = Wo;
+    d.kh = kernel_h; d.kw = kernel_w; d.sy = stride_h; d.sx = stride_w; d.py = pad_h; d.px = pad_w; d.dily = dilation_h; d.dilx = dilation_w;
+    d.K = kk * Cp; d.ldw = ldw; d.Cout = Co; d.omLd = omld; d.omSigmoid = 0; d.outLd = 0; d.outNCHW = 1; d.act = CP_ACT_NONE; d.tile = 0;
+    CP_CALL(cp_dcn_v2_f32(&d, x.data_ptr<float>(), om.data_ptr<float>(), wp.data_ptr<float>(), scale.data_ptr<float>(),
+                          shift.data_ptr<float>(), out.data_ptr<float>(), cur_stream(input)), "cp_dcn_v2_f32");
+    return out;
+}
+
+std::vector<at::Tensor> dcn_v2_backward(const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&,
+                                        const at::Tensor&, int, int, int, int, int, int, int, int, int)
+{
+    TORCH_CHECK(false, "dcn_v2_backward: training is out of scope of the MI355X inference hot path");
+}
+
+at::Tensor multi_pose_decode(const at::Tensor& heat, const at::Tensor& wh, const at::Tensor& kps, const c10::optional<at::Tensor>& reg,
+                             const c10::optional<at::Tensor>& hm_hp, const c10::optional<at::Tensor>& hp_offset, int K)
+{
+    TORCH_CHECK(hm_hp.has_value(), "name 'hm_score' is not defined (hm_hp is mandatory: lib/models/decode.py:265,307)");
+    check_gpu_f32(heat, "heat"); check_gpu_f32(wh, "wh"); check_gpu_f32(kps, "kps"); check_gpu_f32(*hm_hp, "hm_hp");
+    const int B = heat.size(0), cat = heat.size(1), H = heat.size(2), W = heat.size(3), J = kps.size(1) / 2;
+    const auto h = heat.contiguous(), w = wh.contiguous(), k = kps.contiguous(), hp = hm_hp->contiguous();
+    at::Tensor r, ho;
+    if (reg.has_value()) { check_gpu_f32(*reg, "reg"); r = reg->contiguous(); }
+    if (hp_offset.has_value()) { check_gpu_f32(*hp_offset, "hp_offset"); ho = hp_offset->contiguous(); }
+    at::Tensor dets = at::empty({B, K, 5 + 3 * J}, heat.options());
+    if (B == 0) return dets;
+    at::Tensor ws = at::empty({B, 1 + J, K}, heat.options()), wi = at::empty({B, 1 + J, K}, heat.options().dtype(at::kInt));
+    CP_CALL(cp_multi_pose_decode_f32(h.data_ptr<float>(), w.data_ptr<float>(), k.data_ptr<float>(), r.defined() ? r.data_ptr<float>() : nullptr,
+                                     hp.data_ptr<float>(), ho.defined() ? ho.data_ptr<float>() : nullptr, B, cat, J, H, W, K,
+                                     dets.data_ptr<float>(), ws.data_ptr<float>(), wi.data_ptr<int>(), cur_stream(heat)),
+            "cp_multi_pose_decode_f32");
+    return dets;
+}
+
+int64_t plan_create(const std::string& path, bool use_graph)
+{
+    cp_plan* p = nullptr;
+    CP_CALL(cp_plan_load(path.c_str(), use_graph ? 1 : 0, &p), "cp_plan_load");
+    return reinterpret_cast<int64_t>(p);
+}
+
+void check_plan_input(cp_plan* p, const at::Tensor& images)
+{
+    int B, H, W;
+    CP_CALL(cp_plan_info(p, &B, &H, &W, nullptr, nullptr), "cp_plan_info");
+    check_gpu_f32(images, "images");
+    TORCH_CHECK(images.dim() == 4 && images.size(0) == B && images.size(1) == 3 && images.size(2) == H && images.size(3) == W &&
+                images.is_contiguous(), "plan was compiled for a contiguous input [", B, ",3,", H, ",", W, "]");
+}
+
+std::vector<at::Tensor> plan_forward(int64_t handle, const at::Tensor& images)
+{
+    cp_plan* p = reinterpret_cast<cp_plan*>(handle);
+    check_plan_input(p, images);
+    void* s = cur_stream(images);
+    CP_CALL(cp_plan_forward(p, images.data_ptr<float>(), s), "cp_plan_forward");
+    int n = 0;
+    CP_CALL(cp_plan_info(p, nullptr, nullptr, nullptr, &n, nullptr), "cp_plan_info");
+    std::vector<at::Tensor> outs;
+    for (int i = 0; i < n; ++i) {                        // fresh tensors owned by the caller (reference behaviour)
+        float* ptr; int shp[4];
+        CP_CALL(cp_plan_output(p, i, &ptr, shp), "cp_plan_output");
+        at::Tensor t = at::empty({shp[0], shp[1], shp[2], shp[3]}, images.options());
+        CP_CALL(cp_memcpy_d2d(t.data_ptr<float>(), ptr, (size_t)t.numel() * 4, s), "cp_memcpy_d2d");
+        outs.push_back(t);
+    }
+    return outs;
+}
+
+at::Tensor plan_process(int64_t handle, const at::Tensor& images, int K)
+{
+    cp_plan* p = reinterpret_cast<cp_plan*>(handle);
+    check_plan_input(p, images);
+    float* ptr; int shp[4];
+    CP_CALL(cp_plan_output(p, 4, &ptr, shp), "cp_plan_output");                   // hm_hp: J planes
+    at::Tensor dets = at::empty({images.size(0), K, 5 + 3 * shp[1]}, images.options());
+    CP_CALL(cp_plan_process(p, images.data_ptr<float>(), K, dets.data_ptr<float>(), cur_stream(images)), "cp_plan_process");
+    return dets;
+}
+
+void plan_destroy(int64_t handle) { cp_plan_destroy(reinterpret_cast<cp_plan*>(handle)); }
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.def("dcn_v2_forward", &dcn_v2_forward, "dcn_v2_forward");       // DCNv2/src/vision.cpp:6
+    m.def("dcn_v2_backward", &dcn_v2_backward, "dcn_v2_backward");    // :7 (raises: inference only)
+    m.def("multi_pose_decode", &multi_pose_decode, py::arg("heat"), py::arg("wh"), py::arg("kps"), py::arg("reg") = py::none(),
+          py::arg("hm_hp") = py::none(), py::arg("hp_offset") = py::none(), py::arg("K") = 100);
+    m.def("plan_create", &plan_create, py::arg("path"), py::arg("use_graph") = true);
+    m.def("plan_forward", &plan_forward);
+    m.def("plan_process", &plan_process, py::arg("handle"), py::arg("images"), py::arg("K") = 100);
+    m.def("plan_destroy", &plan_destroy);
+}

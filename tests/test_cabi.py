@@ -52,3 +52,20 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), f
+
+
+def test_torch_extension_module_ext(lib):
+    """the pybind module `_ext` built with torch.utils.cpp_extension (what DCNv2/dcn_v2.py:12 imports) exports the
+    reference's dcn_v2_forward / dcn_v2_backward plus multi_pose_decode and the plan entry points, and refuses CPU tensors
+    (the reference has no CPU implementation either: cpu/dcn_v2_cpu.cpp:7-24)."""
+    import torch
+    from centerpose_amd import _ext
+    for n in ("dcn_v2_forward", "dcn_v2_backward", "multi_pose_decode", "plan_create", "plan_forward", "plan_process", "plan_destroy"):
+        assert callable(getattr(_ext, n))
+    z = torch.zeros
+    with pytest.raises(RuntimeError, match="GPU"):
+        _ext.dcn_v2_forward(z(1, 4, 5, 5), z(2, 4, 3, 3), z(2), z(1, 18, 5, 5), z(1, 9, 5, 5), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError, match="hm_score"):
+        _ext.multi_pose_decode(z(1, 1, 4, 4), z(1, 2, 4, 4), z(1, 34, 4, 4))
+    with pytest.raises(RuntimeError):
+        _ext.plan_create("/nonexistent.cpplan", True)

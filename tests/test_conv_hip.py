@@ -307,6 +307,29 @@ def test_dcn_v2_forward_ext_dropin(C, Co, k, s, p, d):
         dcn_v2_ext.dcn_v2_forward(t[0].cpu(), *t[1:], k, k, s, s, p, p, d, d, 1)
 
 
+@pytest.mark.parametrize("C,Co,k,s,p,d", [(8, 6, 3, 1, 1, 1), (16, 32, 3, 2, 1, 1), (64, 64, 3, 1, 1, 1), (5, 7, 1, 1, 0, 1)])
+def test_pybind_ext_dcn_v2_forward(C, Co, k, s, p, d):
+    """The compiled pybind module `_ext` (torch cpp_extension; DCNv2/src/vision.cpp:4-9) with the reference's 14-argument call."""
+    from centerpose_amd import _ext
+    from oracle import dcn as odcn
+    r = np.random.RandomState(C * 5 + k)
+    B, H, W = 2, 11, 9
+    Ho = (H + 2 * p - (d * (k - 1) + 1)) // s + 1
+    Wo = (W + 2 * p - (d * (k - 1) + 1)) // s + 1
+    x = r.randn(B, C, H, W).astype(np.float32)
+    w = (r.randn(Co, C, k, k) * 0.2).astype(np.float32)
+    b = r.randn(Co).astype(np.float32)
+    off = (r.randn(B, 2 * k * k, Ho, Wo) * 2).astype(np.float32)
+    m = r.rand(B, k * k, Ho, Wo).astype(np.float32)
+    ref = odcn.dcn_v2_forward_c(x, w, b, off, m, k, k, s, s, p, p, d, d, 1)
+    t = [torch.from_numpy(a).cuda() for a in (x, w, b, off, m)]
+    out = _ext.dcn_v2_forward(*t, k, k, s, s, p, p, d, d, 1)
+    assert out.shape == ref.shape and out.is_cuda
+    _close(out, torch.from_numpy(ref), 1e-4)
+    with pytest.raises(RuntimeError):
+        _ext.dcn_v2_backward(*t, t[0], k, k, s, s, p, p, d, d, 1)
+
+
 @pytest.mark.parametrize("cin,cout,hw,B", [(16, 16, (24, 40), 2), (16, 64, (8, 16), 1), (64, 64, (20, 28), 3), (32, 27, (16, 16), 2),
                                            (48, 128, (9, 35), 2), (128, 192, (16, 16), 2)])
 def test_conv3x3_patch_kernel(cin, cout, hw, B):

@@ -199,6 +199,31 @@ def test_c_plan_handle_runs_network_without_engine(arch, tmp_path):
         assert np.array_equal(got["dets"], ref_dets.cpu().numpy())
 
 
+def test_pybind_ext_plan_and_decode(tmp_path, golden_dir):
+    """`_ext.plan_create / plan_forward / plan_process / plan_destroy` and `_ext.multi_pose_decode`."""
+    import cases
+    from centerpose_amd import _ext, engine, synth
+    from centerpose_amd.decode import multi_pose_decode
+    x = synth.make_images(2, 128, 128, seed=4).cuda()
+    eng = engine.Engine("res_50", synth.make_state_dict("res_50"), 2, 128, 128, use_graph=False)
+    ref = [t.clone() for t in eng(x)]
+    ref_dets = multi_pose_decode(ref[0], ref[1], ref[2], reg=ref[3], hm_hp=ref[4], hp_offset=ref[5], K=100)
+    path = str(tmp_path / "p.cpplan")
+    eng.save_plan(path)
+    h = _ext.plan_create(path, True)
+    for _ in range(3):
+        outs = _ext.plan_forward(h, x)
+        dets = _ext.plan_process(h, x, 100)
+    torch.cuda.synchronize()
+    assert len(outs) == 6 and all(torch.equal(a, b) for a, b in zip(outs, ref)) and torch.equal(dets, ref_dets)
+    _ext.plan_destroy(h)
+    gen, kw, K, use_reg, use_off = cases.DECODE_CASES["rand_b2"]
+    g = np.load(os.path.join(golden_dir, "decode_rand_b2.npz"))
+    t = {k: torch.from_numpy(v).cuda() for k, v in gen(**kw).items()}
+    d = _ext.multi_pose_decode(t["hm"], t["wh"], t["hps"], t["reg"], t["hm_hp"], t["hp_offset"], K)
+    assert np.array_equal(d.cpu().numpy(), g["dets"])
+
+
 def test_c_plan_rejects_bad_files(tmp_path):
     from centerpose_amd import cplan
     from centerpose_amd._lib import CenterposeHipError
