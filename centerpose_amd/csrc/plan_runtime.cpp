@@ -205,8 +205,8 @@ extern "C" int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_
         Ref f;
         f.kind = rd.u32(); f.id = rd.u32(); f.off = rd.u64(); f.numel = rd.u64();
         if (f.kind == REF_NULL) return nullptr;
-        if (f.kind == REF_BUF && f.id < nbuf && f.off < buf_numel[f.id]) return pl->bufs[f.id] + f.off;
-        if (f.kind == REF_CONST && f.id < nconst) return pl->consts[f.id];
+        if (f.kind == REF_BUF && f.id < nbuf && f.off < buf_numel[f.id] && f.numel <= buf_numel[f.id] - f.off) return pl->bufs[f.id] + f.off;
+        if (f.kind == REF_CONST && f.id < nconst && f.numel <= ci[f.id].numel) return pl->consts[f.id];
         bad_ref = true;
         return nullptr;
     };

@@ -164,9 +164,9 @@ def parse(blob):
 
     def check_ref(ref):
         kind, i, off, n = ref
-        if kind == REF_BUF and (i >= nbuf or off >= buffers[i]):
+        if kind == REF_BUF and (i >= nbuf or off >= buffers[i] or n > buffers[i] - off):
             raise ValueError("plan file: buffer reference out of range")
-        if kind == REF_CONST and i >= nconst:
+        if kind == REF_CONST and (i >= nconst or n > consts[i][0]):
             raise ValueError("plan file: constant reference out of range")
         if kind not in (REF_NULL, REF_BUF, REF_CONST):
             raise ValueError("plan file: bad reference kind %d" % kind)
