@@ -338,6 +338,7 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
         case 128032: rc = launch_dcn<128, 32, 4, 1, 32>(a, s); break;
         case 128064: rc = launch_dcn<128, 64, 2, 2, 32>(a, s); break;
         case 64064: rc = launch_dcn<64, 64, 2, 2, 32>(a, s); break;
+        case 64032: rc = launch_dcn<64, 32, 4, 1, 16>(a, s); break;
         case 128128: rc = launch_dcn<128, 128, 2, 2, 32>(a, s); break;
         case 64128: rc = launch_dcn<64, 128, 2, 2, 32>(a, s); break;
         case 2064064: rc = launch_dcn<64, 64, 2, 2, 32, 2>(a, s); break;      // 32-channel (full cache line) gathers

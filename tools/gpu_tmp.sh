@@ -1,2 +1,3 @@
 #!/bin/bash
-for ns in 3 4; do echo "CP_STREAMS=$ns"; CP_STREAMS=$ns timeout 200 python bench.py --arch hrnet --batch 8 --no-cpu-baseline --no-profile 2>&1 | tail -5 | cut -c1-300; done
+for sm in 0 300 600 1100; do CP_DCN_SMALL=$sm timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
+import json,sys; l=json.loads(sys.stdin.read()); ks=[(n,v) for n,v in l['roofline']['kernels'].items() if n.startswith('dcn')]; print('small<$sm', l['value'], [(n[16:30], v['launches'], v['ms_per_step'], v['executed_tflops']) for n,v in ks])"; done
