@@ -298,6 +298,24 @@ class PlanBuilder(nets.Graph):
         return outs
 
 
+class _DagGraph:
+    """Owner of a cp_graph handle with torch.cuda.CUDAGraph's `replay()`."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    def replay(self):
+        _lib.check(_lib.lib().cp_graph_launch(self.h, _lib.stream()), "cp_graph_launch")
+
+    def __del__(self):
+        try:
+            if self.h:
+                _lib.lib().cp_graph_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
 class Engine:
     """Static-shape inference engine for one (arch, batch, H, W)."""
 
@@ -422,9 +440,49 @@ class Engine:
         # streams / events must outlive the capture (destroying a capturing stream before hipStreamEndCapture crashes)
         self._capture_refs = (streams, events, fork)
 
+    def build_dag_graph(self):
+        """hipGraph with one node per launch and explicit edges from `dependencies()` (csrc/graph_builder.cpp): the whole
+        DAG instead of what two capture streams can express.  Returns a `_DagGraph` with `.replay()`."""
+        import ctypes
+        L = _lib.lib()
+        L.cp_graph_stream.restype = ctypes.c_void_p
+        deps = self.dependencies()
+        # transitive reduction: an edge j -> i is dropped when i already follows j through another predecessor (every edge
+        # that crosses executor streams is an event wait at replay time)
+        n = len(deps)
+        reach = [set() for _ in range(n)]                 # all ancestors
+        red = []
+        for i in range(n):
+            keep = []
+            for j in sorted(deps[i], reverse=True):
+                if not any(j in reach[k] for k in keep):
+                    keep.append(j)
+            for j in deps[i]:
+                reach[i].add(j)
+                reach[i] |= reach[j]
+            red.append(sorted(keep))
+        deps = red
+        g = ctypes.c_void_p()
+        _lib.check(L.cp_graph_create(ctypes.byref(g)), "cp_graph_create")
+        try:
+            cap = ctypes.c_void_p(L.cp_graph_stream(g))
+            for i, (_, _, _, launch) in enumerate(self.launches):
+                _lib.check(L.cp_graph_begin_node(g), "cp_graph_begin_node")
+                launch.run(cap)
+                d = (ctypes.c_int * max(1, len(deps[i])))(*deps[i])
+                nid = ctypes.c_int(-1)
+                _lib.check(L.cp_graph_end_node(g, d, len(deps[i]), ctypes.byref(nid)), "cp_graph_end_node")
+                assert nid.value == i
+            _lib.check(L.cp_graph_instantiate(g), "cp_graph_instantiate")
+        except Exception:
+            L.cp_graph_destroy(g)
+            raise
+        return _DagGraph(g)
+
     def capture(self):
         """Capture the whole schedule into one hipGraph (launch-bound inner loop -> one replay).  With
-        `self.nstreams > 1` (CP_STREAMS, default 2) independent branches are captured on parallel streams."""
+        `self.nstreams > 1` (CP_STREAMS, default 2) independent branches are captured on parallel streams;
+        CP_GRAPH=dag builds the graph node by node from the data dependencies instead (`build_dag_graph`)."""
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -436,6 +494,10 @@ class Engine:
         # HRNet graphs - not for ResNet-50 or a minimal reproducer - so the default stays at two.)
         nstreams = getattr(self, "nstreams", None) or int(os.environ.get("CP_STREAMS", "2"))
         g = None
+        if os.environ.get("CP_GRAPH", "") == "dag":
+            self.graph = self.build_dag_graph()
+            self.stream_of_launch = [0] * len(self.launches)
+            return
         if nstreams > 1:
             deps = self.dependencies()
             try:

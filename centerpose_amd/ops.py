@@ -60,10 +60,11 @@ class Launch:
         ptrs = [_lib.vptr(t) if t is not None else _lib.c_void_p(0) for t in self.tensors]
         self._args = marshal(self.fn, self.desc, ptrs, self.ints)
 
-    def run(self):
+    def run(self, stream=None):
+        """Enqueue on torch's current stream (or on the raw hipStream_t `stream`, a ctypes.c_void_p)."""
         if self._cfn is None:
             self.bind()
-        _lib.check(self._cfn(*self._args, _lib.stream()), self.fn)
+        _lib.check(self._cfn(*self._args, stream if stream is not None else _lib.stream()), self.fn)
         if self.kernel is None:
             self.kernel = _lib.lib().cp_last_kernel().decode()
 

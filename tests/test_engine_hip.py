@@ -258,6 +258,21 @@ def test_multistream_capture_is_bit_identical(arch):
         assert all(torch.equal(p, q) for p, q in zip(outs[0], o))
 
 
+def test_dag_graph_is_bit_identical(monkeypatch):
+    """CP_GRAPH=dag: the hipGraph assembled node by node from the data dependencies (csrc/graph_builder.cpp, transitively
+    reduced edges) replays the same bits as the eager schedule."""
+    from centerpose_amd import engine, synth
+    sd = synth.make_state_dict("hrnet")
+    x = synth.make_images(2, 128, 128).cuda()
+    ref = [t.clone() for t in engine.Engine("hrnet", sd, 2, 128, 128, use_graph=False)(x)]
+    monkeypatch.setenv("CP_GRAPH", "dag")
+    e = engine.Engine("hrnet", sd, 2, 128, 128, use_graph=True)
+    for _ in range(3):
+        out = e(x)
+    torch.cuda.synchronize()
+    assert isinstance(e.graph, engine._DagGraph) and all(torch.equal(a, b) for a, b in zip(ref, out))
+
+
 def test_full_size_batch_invariance_and_scaling_property():
     """Size-independent properties at BASELINE's full 512x512 size (the oracle is too slow there): (1) an image's head
     maps do not depend on which batch it travels in - B=4 in one engine == the same images through a B=2 engine, bit for
