@@ -147,6 +147,67 @@ __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, co
     }
 }
 
+// ---- fused head: [3x3 conv + bias + ReLU] -> 1x1 conv (+ bias, + sigmoid) without the intermediate ever leaving the CU ----
+// lib/models/heads/keypoint.py:14-37: every branch is conv3x3(C -> head_conv) -> ReLU -> conv1x1(head_conv -> n).  For the
+// branches with n <= 2 outputs (hm, wh, reg, hp_offset) the 1x1 is applied HERE, on the channel tile that has just been reduced:
+// each thread multiplies its 4 channels of 4 output pixels with the matching 1x1 weights and keeps 4 * N2 partial sums in
+// registers across the block's channel tiles; at the end the 8 lanes that share a pixel are summed with three xor-shuffles
+// (fixed order: deterministic) and lane 0 writes the reference's NCHW output.  The 268 MB mid tensor of a B = 16 head (written
+// by this kernel, read back by the 1x1 launch: 2 x 268 MB per head) no longer exists for those four branches.
+struct WgHead {
+    const float* w2;     // [N2][ld2] 1x1 weights, row-major over the mid channels
+    const float* b2;     // [N2]
+    float* out2;         // NCHW [B][n2][H][W]
+    int n2, ld2, act2;
+};
+
+template <int N2>
+__device__ __forceinline__ void wg_output_tile_head(const ConvArgs& a, const WgHead& hd, float* red, const f32x16 (&acc)[4], int xi, int h,
+                                                    int m, int tid, int yb, int x0, int tile, float (&acc2)[2][2][N2])
+{
+    float* wp = red + (xi * 64 + m) * WG_LDR + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        wg_v4 q[4];
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) q[nu] = (wg_v4){acc[nu][4 * j], acc[nu][4 * j + 1], acc[nu][4 * j + 2], acc[nu][4 * j + 3]};
+        *reinterpret_cast<wg_v4*>(wp + 8 * j) = (q[0] + q[1]) + q[2];
+        *reinterpret_cast<wg_v4*>(wp + 32 * WG_LDR + 8 * j) = (q[1] - q[2]) - q[3];
+    }
+    int itn[2], itrd[2];
+    wg_v4 sc[2], sh[2], w2r[2][N2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + it * IG_THREADS;
+        const int n4 = item & 7, bb = (item >> 3) & 1, mi = item >> 4;
+        itn[it] = tile * 32 + n4 * 4;
+        itrd[it] = (bb * 32 + mi) * WG_LDR + n4 * 4;
+        sc[it] = *reinterpret_cast<const wg_v4*>(a.scale + itn[it]);
+        sh[it] = *reinterpret_cast<const wg_v4*>(a.shift + itn[it]);
+#pragma unroll
+        for (int j = 0; j < N2; ++j) w2r[it][j] = *reinterpret_cast<const wg_v4*>(hd.w2 + (size_t)j * hd.ld2 + itn[it]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const float* rp = red + itrd[it];
+        const wg_v4 q0 = wg_lds4(rp), q1 = wg_lds4(rp + 64 * WG_LDR), q2 = wg_lds4(rp + 128 * WG_LDR), q3 = wg_lds4(rp + 192 * WG_LDR);
+        wg_v4 yv[2];
+        yv[0] = (q0 + q1) + q2;
+        yv[1] = (q1 - q2) - q3;
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa) {
+            wg_v4 v = __builtin_elementwise_fma(yv[aa], sc[it], sh[it]);
+            v = __builtin_elementwise_max(v, (wg_v4){0.f, 0.f, 0.f, 0.f});        // the head's ReLU (keypoint.py:17,21,...)
+#pragma unroll
+            for (int j = 0; j < N2; ++j) {
+                const wg_v4 w = w2r[it][j];
+                acc2[it][aa][j] = fmaf(v.w, w.w, fmaf(v.z, w.z, fmaf(v.y, w.y, fmaf(v.x, w.x, acc2[it][aa][j]))));
+            }
+        }
+    }
+}
+
 // MT = 32-tile M sets per block (block = 8*MT x 16 output pixels), NT = 32-channel N tiles per block,
 // KS = channels per LDS stage, NB = U-fragment register sets (prefetch distance NB-1 chunks).
 // The U fragment of a chunk is used by MT MFMAs, the V fragment by NT: U traffic per flop ~ 1/MT,
@@ -365,7 +426,8 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
 #define WGV_CG (10 * WG_PWP * 4)                            // floats per 4-channel plane
 #define WGV_SMEM_FLOATS (2 * WG_RED)                        // two reduction buffers (73.7 KB) >= the 51.2 KB patch
 
-__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const ConvArgs a, const WgGrid gd, int NL)
+template <int N2>       // 0: plain conv; 1 / 2: fused head with N2 output channels of the 1x1 (wg_output_tile_head)
+__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const ConvArgs a, const WgGrid gd, int NL, const WgHead hd)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -445,6 +507,13 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
     __syncthreads();                // every wave has read its rows of the patch: the region becomes the reduction buffers
     // ---- output-channel tiles: U streams through two register sets, V stays put
     int lin = 0;
+    float acc2[2][2][N2 > 0 ? N2 : 1];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < (N2 > 0 ? N2 : 1); ++j) acc2[i][k][j] = 0.f;
 #pragma unroll 1
     for (int nt = nt0; nt < nt1; ++nt) {
         f32x16 acc[4];
@@ -475,7 +544,30 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
             __builtin_amdgcn_sched_barrier(0);
         }
         // two reduction buffers: tile i+2 overwrites buffer i&1 only after the barrier inside tile i+1's output stage
-        wg_output_tile(a, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, b, y0, x0, nt, true);
+        if constexpr (N2 > 0) wg_output_tile_head<N2>(a, hd, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, y0, x0, nt, acc2);
+        else wg_output_tile(a, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, b, y0, x0, nt, true);
+    }
+    if constexpr (N2 > 0) {
+        // the 8 lanes tid & 7 = 0..7 hold the partial sums of one (tile, column) over 32 channels each: sum them in a fixed
+        // order, add the bias, apply the output activation and store the reference's NCHW planes
+        const size_t HW = (size_t)a.H * a.W;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int item = tid + it * IG_THREADS;
+            const int bb = (item >> 3) & 1, mi = item >> 4;
+            const int ox = x0 + 2 * (mi & 7) + bb, oy = y0 + 2 * (mi >> 3);
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+#pragma unroll
+                for (int j = 0; j < N2; ++j) {
+                    float v = acc2[it][aa][j];
+                    v += __shfl_xor(v, 1);
+                    v += __shfl_xor(v, 2);
+                    v += __shfl_xor(v, 4);
+                    if ((tid & 7) == 0 && j < hd.n2 && ox < a.W && oy + aa < a.H)
+                        hd.out2[((size_t)b * hd.n2 + j) * HW + (size_t)(oy + aa) * a.W + ox] = cp_act(v + hd.b2[j], hd.act2);
+                }
+        }
     }
 }
 
@@ -508,12 +600,13 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
     return 0;
 }
 
-static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups)
+template <int N2>
+static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups, const WgHead& hd)
 {
     const int smem = WGV_SMEM_FLOATS * 4;
     static bool attr = false;
     if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_vs64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_vs64_kernel<N2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) { cp_set_error("conv3x3_winograd: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
         attr = true;
     }
@@ -528,9 +621,24 @@ static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups)
     const long long grid = (long long)a.B * gd.tilesX * gd.tilesY * gd.ntb;
     const long long dmax = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
     if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd: grid %lld too large", grid); return 1; }
-    hipLaunchKernelGGL(conv3x3_wino_vs64_kernel, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd, NL);
-    cp_note_kernel("conv3x3_wino_vs64_kernel");
+    hipLaunchKernelGGL(conv3x3_wino_vs64_kernel<N2>, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd, NL, hd);
+    cp_note_kernel(N2 ? "conv3x3_wino_vs64_kernel<%d>" : "conv3x3_wino_vs64_kernel<0>", N2);
     return 0;
+}
+
+// [3x3 conv + bias + ReLU] + 1x1 conv of a KeypointHead branch with n2 <= 2 outputs in one launch.  Returns -1 when the shape is
+// not the fused kernel's (64 input channels, mid channels a multiple of 32, NHWC, 16-byte aligned operands).
+int cp_launch_head3x3_1x1(const ConvArgs& a, const float* w2, const float* b2, float* out2, int n2, int ld2, int act2, hipStream_t s)
+{
+    const bool ok = a.nsrc == 1 && a.kh == 3 && a.kw == 3 && a.sy == 1 && a.sx == 1 && a.py == 1 && a.px == 1 && a.Ho == a.H &&
+                    a.Wo == a.W && a.srcC[0] == 64 && a.srcLd[0] % 4 == 0 && a.Cout % 32 == 0 && a.act == CP_ACT_RELU && !a.res &&
+                    n2 >= 1 && n2 <= 2 && ld2 % 4 == 0 && ld2 >= a.Cout &&
+                    (((size_t)a.src[0] | (size_t)a.w | (size_t)w2 | (size_t)a.scale | (size_t)a.shift) & 15) == 0 &&
+                    (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
+    if (!ok) return -1;
+    WgHead hd;
+    hd.w2 = w2; hd.b2 = b2; hd.out2 = out2; hd.n2 = n2; hd.ld2 = ld2; hd.act2 = act2;
+    return n2 == 1 ? launch_wino_vs64<1>(a, s, 1, hd) : launch_wino_vs64<2>(a, s, 1, hd);
 }
 
 // a.w = Winograd-domain weights from cp_winograd_pack_f32.  Returns -1 when the shape is not eligible.
@@ -554,7 +662,7 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
         else variant = ntiles == 1 ? 11 : 12;
     }
     // 64xx: V-stationary kernel (C == 64), xx = number of channel-tile groups per spatial tile (0 -> 1)
-    if (variant >= 6400 && variant < 6500) return a.srcC[0] == 64 ? launch_wino_vs64(a, s, variant - 6400) : -1;
+    if (variant >= 6400 && variant < 6500) return a.srcC[0] == 64 ? launch_wino_vs64<0>(a, s, variant - 6400, WgHead{}) : -1;
     switch (variant) {
         case 11: return launch_wino<1, 1, 16, 2>(a, s);
         case 12: return launch_wino<1, 2, 16, 2>(a, s);

@@ -325,6 +325,23 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
 
 // Winograd F(2x2,3x3) path (conv3x3_wino.hip): same descriptor, `u` = cp_winograd_pack_f32 output.
 // d->tile: 0 = auto, 1 / 2 = 32 / 64 output channels per block.
+// KeypointHead branch (lib/models/heads/keypoint.py:14-37) with n2 <= 2 outputs as ONE launch: d / src / u / scale / shift describe the
+// 3x3 conv (C = 64 -> Cmid, bias in `shift`, act = ReLU) exactly as for cp_conv3x3_winograd_f32; w2 [n2][ld2] / b2 [n2] are the
+// 1x1 conv; out2 is the reference's NCHW output [B, n2, H, W]; act2 = CP_ACT_SIGMOID for hm (multi_pose.py:35-37).
+extern "C" int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
+                                  const float* w2, const float* b2, float* out2, int n2, int ld2, int act2, void* stream)
+{
+    ConvArgs a;
+    const float* srcs[1] = {src};
+    CP_CHECK_ARG(d && d->nsrc == 1 && !d->inNCHW && w2 && b2 && out2, "head3x3_1x1: one NHWC source and the 1x1 operands expected");
+    if (int rc = conv_args_from_desc(d, srcs, u, scale, shift, nullptr, out2, a)) return rc;
+    const int rc = cp_launch_head3x3_1x1(a, w2, b2, out2, n2, ld2, act2, (hipStream_t)stream);
+    CP_CHECK_ARG(rc >= 0, "head3x3_1x1: shape not eligible (C = 64, Cmid %% 32 == 0, ReLU, n2 <= 2, 16-byte aligned operands)");
+    if (rc) return rc;
+    CP_CHECK_LAUNCH("conv3x3_wino_vs64_kernel");
+    return 0;
+}
+
 extern "C" int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale,
                                        const float* shift, const float* res, float* out, void* stream)
 {

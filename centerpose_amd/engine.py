@@ -75,6 +75,7 @@ class PlanBuilder(nets.Graph):
         self.launches = []      # (kind, name, algorithmic flops_per_batch, ops.Launch); kind 'wino' = 3x3 conv on the Winograd kernel
         # CP_WINOGRAD=0 keeps every 3x3 on the direct (patch) kernel: A/B switch for tests and profiling
         self.winograd = os.environ.get("CP_WINOGRAD", "1") != "0"
+        self.fuse_heads = os.environ.get("CP_FUSE_HEADS", "1") != "0"      # 3x3 + 1x1 of the <= 2-output head branches in one launch
         self._pool_cache = {}
         self.outputs = None
 
@@ -285,6 +286,14 @@ class PlanBuilder(nets.Graph):
                 wp3h = ops.pack_conv_weight(self.expand_in(self.w("%s.%s.0.weight" % (p, h)), [feat]))
                 sc3h, sh3h = ops.fold_bn(hc, None, self.w("%s.%s.0.bias" % (p, h)), self.dev)
                 u3h = self.wino(wp3h, feat.t.shape[3], hc)
+                if u3h is not None and self.fuse_heads and ops.head3x3_1x1_eligible(ft, hc, n):
+                    # branches with <= 2 outputs (hm, wh, reg, hp_offset): the 1x1 rides in the Winograd kernel's epilogue,
+                    # the [B,H,W,hc] intermediate (268 MB at B = 16) is neither written nor read back
+                    w2 = self.w("%s.%s.2.weight" % (p, h)).reshape(n, hc).contiguous()
+                    self.add("wino", "%s.%s.0+2" % (p, h), 2 * H * W * (hc * feat.C * 9 + n * hc),
+                             ops.head3x3_1x1_launch(ft, u3h, sc3h, sh3h, w2, self.w("%s.%s.2.bias" % (p, h)), o, hc=hc, act2=act))
+                    outs.append(o)
+                    continue
                 self.add("wino" if u3h is not None else "conv", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9,
                          ops.conv2d_launch([ft], wp3h, sc3h, sh3h, mid.t, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU,
                                            wino=u3h))

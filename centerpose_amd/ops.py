@@ -78,6 +78,8 @@ def marshal(fn, desc, ptrs, ints):
         return [d, srcs] + ptrs[4:]
     if fn in ("cp_conv3x3_winograd_f32", "cp_dcn_v2_f32"):      # desc + pointers in order
         return [d] + ptrs
+    if fn == "cp_head3x3_1x1_f32":                # ptrs: src, u, scale, shift, w2, b2, out2; ints: n2, ld2, act2
+        return [d] + ptrs + ints
     if fn == "cp_stem7x7_f32":                    # ptrs: x, w, scale, shift, out; ints: B, H, W, Cout, stride, outLd, relu
         return ptrs + ints
     if fn == "cp_maxpool2d_nhwc_f32":             # ptrs: in, out; ints: inLd, outLd, B, H, W, C, k, s, p
@@ -102,7 +104,7 @@ def marshal(fn, desc, ptrs, ints):
 
 FN_IDS = {"cp_conv2d_f32": 1, "cp_conv3x3_winograd_f32": 2, "cp_dcn_v2_f32": 3, "cp_stem7x7_f32": 4,
           "cp_maxpool2d_nhwc_f32": 5, "cp_dw_deconv_add_nhwc_f32": 6, "cp_sum_up_nhwc_f32": 7, "cp_dwconv2d_nhwc_f32": 8,
-          "cp_global_avgpool_nhwc_f32": 9, "cp_scale_add_nhwc_f32": 10, "cp_shuffle_concat_nhwc_f32": 11}
+          "cp_global_avgpool_nhwc_f32": 9, "cp_scale_add_nhwc_f32": 10, "cp_shuffle_concat_nhwc_f32": 11, "cp_head3x3_1x1_f32": 12}
 
 
 def pad_rows(t, ldw):
@@ -219,6 +221,31 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
         assert len(srcs) == 1 and not in_nchw
         return Launch("cp_conv3x3_winograd_f32", d, [srcs[0], wino, scale, shift, res, out])
     return Launch("cp_conv2d_f32", d, list(srcs) + [None] * (4 - len(srcs)) + [wp, scale, shift, res, out])
+
+
+def head3x3_1x1_eligible(x, hc, n2):
+    """the fused head launch: 64 physical input channels, mid channels a multiple of 32, at most two outputs, and enough
+    spatial tiles to fill the chip (the V-stationary Winograd kernel's own condition)."""
+    B, H, W, C = x.shape
+    return C == 64 and hc % 32 == 0 and hc >= 128 and 1 <= n2 <= 2 and B * ((H + 7) // 8) * ((W + 15) // 16) >= 512
+
+
+def head3x3_1x1_launch(x, u, scale, shift, w2, b2, out2, *, hc, act2=ACT_NONE):
+    """One KeypointHead branch (3x3 conv + bias + ReLU -> 1x1 conv + bias [+ sigmoid]) with n2 <= 2 outputs in one launch.
+    x NHWC [B,H,W,64]; u = pack_wino_weight(3x3 weights); scale / shift [>= hc]; w2 [n2, ld2] contiguous; out2 NCHW [B,n2,H,W]."""
+    B, H, W, C = x.shape
+    n2, ld2 = w2.shape
+    assert out2.is_contiguous() and tuple(out2.shape) == (B, n2, H, W) and w2.is_contiguous() and b2.numel() >= n2
+    d = ConvDesc()
+    d.nsrc = 1
+    d.srcC[0], d.srcLd[0] = C, _ld(x)
+    d.B, d.H, d.W, d.Ho, d.Wo = B, H, W, H, W
+    d.kh, d.kw, d.sy, d.sx, d.py, d.px = 3, 3, 1, 1, 1, 1
+    d.K, d.ldw, d.Cout = 9 * C, round_up(hc, 64), hc
+    d.resLd, d.outLd, d.outNCHW = 0, hc, 0
+    d.OH, d.OW, d.osy, d.osx, d.ooy, d.oox = H, W, 1, 1, 0, 0
+    d.act, d.inNCHW, d.tile, d.nsub = ACT_RELU, 0, 0, 1
+    return Launch("cp_head3x3_1x1_f32", d, [x, u, scale, shift, w2, b2, out2], [n2, ld2, act2])
 
 
 def wino_eligible(cin, k, stride, pad, nsrc=1):

@@ -73,6 +73,14 @@ int cp_winograd_pack_f32(const float* w, float* u, int C, int Cout, void* stream
 int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
                             const float* res, float* out, void* stream);
 
+/* One KeypointHead branch (lib/models/heads/keypoint.py:14-37: conv3x3(C -> head_conv, bias) -> ReLU -> conv1x1(head_conv -> n, bias))
+ * with n <= 2 outputs -- hm, wh, reg, hp_offset -- as ONE launch: the 1x1 is applied to every channel tile of the Winograd kernel
+ * while it is on the CU, the [B,H,W,head_conv] intermediate is never written.  d / src / u / scale / shift: the 3x3 conv as for
+ * cp_conv3x3_winograd_f32 (C = 64, act = CP_ACT_RELU); w2: [n2][ld2] (ld2 >= head_conv, % 4 == 0), b2: [n2]; out2: NCHW
+ * [B,n2,H,W]; act2: CP_ACT_SIGMOID for hm (lib/detectors/multi_pose.py:35-37), else CP_ACT_NONE.  Returns 1 for other shapes. */
+int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
+                       const float* w2, const float* b2, float* out2, int n2, int ld2, int act2, void* stream);
+
 /* ---- fused DCNv2 forward -------------------------------------------------------------------------
  * Replaces dcn_v2_forward / dcn_v2_cuda_forward (DCNv2/src/dcn_v2.h:9-39, src/cuda/dcn_v2_cuda.cu:42-172,
  * src/cuda/dcn_v2_im2col_cuda.cu:25-54,125-195) plus the BN + ReLU of DeformConv (pose_dla_dcn.py:345-348).

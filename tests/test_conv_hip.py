@@ -386,6 +386,31 @@ def test_conv3x3_winograd_kernel(cin, cout, hw, B, nt):
         assert torch.isnan(buf[..., cout:]).all()      # nothing stored past Cout
 
 
+@pytest.mark.parametrize("B,H,W,hc,n2,act2", [(2, 32, 48, 256, 1, 2), (1, 37, 45, 256, 2, 0), (3, 8, 16, 128, 2, 0), (1, 19, 9, 64 * 5, 1, 2)])
+def test_head3x3_1x1_fused(B, H, W, hc, n2, act2):
+    """One KeypointHead branch with <= 2 outputs in ONE launch (keypoint.py:14-37: conv3x3 + bias -> ReLU -> conv1x1 + bias; hm
+    gets its sigmoid, multi_pose.py:35-37): the 1x1 rides in the Winograd kernel's epilogue.  Ragged tiles, 1 and 2 outputs."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + H + n2)
+    x = torch.randn(B, 64, H, W, generator=g)
+    w3 = torch.randn(hc, 64, 3, 3, generator=g) / 24.0
+    b3 = torch.randn(hc, generator=g) * 0.1
+    w1 = torch.randn(n2, hc, 1, 1, generator=g) / hc ** 0.5
+    b1 = torch.randn(n2, generator=g)
+    ref = F.conv2d(F.relu(F.conv2d(x, w3, b3, 1, 1)), w1, b1)
+    if act2 == 2:
+        ref = torch.sigmoid(ref)
+    wp3 = ops.pack_conv_weight(w3.cuda())
+    u = ops.pack_wino_weight(wp3, 64, hc)
+    sc, sh = ops.fold_bn(hc, None, b3.cuda())
+    out = torch.full((B, n2, H, W), float("nan"), device="cuda")
+    ops.head3x3_1x1_launch(_nhwc(x), u, sc, sh, w1.reshape(n2, hc).contiguous().cuda(), b1.cuda(), out, hc=hc, act2=act2).run()
+    _close(out, ref, 2e-5 if act2 == 2 else 1e-4)
+    a = out.clone()
+    ops.head3x3_1x1_launch(_nhwc(x), u, sc, sh, w1.reshape(n2, hc).contiguous().cuda(), b1.cuda(), out, hc=hc, act2=act2).run()
+    assert torch.equal(a, out)             # fixed summation order: deterministic
+
+
 def test_conv3x3_winograd_fuzz_vs_direct_kernel():
     """Seeded random shapes (odd H/W, batch 1..3, ragged channel tiles, strided input / output / residual views, every
     activation, every block shape): the Winograd kernel against the direct halo-patch kernel on the same buffers."""

@@ -174,8 +174,9 @@ print("child ok", p.n_launches)
 """
 
 
-@pytest.mark.parametrize("arch", ["dla_34", "hrnet", "mobilenetv3", "shufflenetV2"])
-def test_c_plan_handle_runs_network_without_engine(arch, tmp_path):
+@pytest.mark.parametrize("arch,B,hw", [("dla_34", 2, 128), ("hrnet", 2, 128), ("mobilenetv3", 2, 128), ("shufflenetV2", 2, 128),
+                                       ("dla_34", 4, 512)])      # 4 x 512 x 512: the fused head launches (cp_head3x3_1x1_f32) are in the plan
+def test_c_plan_handle_runs_network_without_engine(arch, B, hw, tmp_path):
     """cp_plan_load / cp_plan_forward / cp_plan_process / cp_plan_destroy.  A fresh interpreter that imports
     neither engine.py nor ops.py runs the plan file through the C ABI alone; heads and dets equal the Python engine's bits."""
     import subprocess
@@ -183,8 +184,9 @@ def test_c_plan_handle_runs_network_without_engine(arch, tmp_path):
     from centerpose_amd import engine, synth
     from centerpose_amd.decode import multi_pose_decode
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    x = synth.make_images(2, 128, 128, seed=21)
-    eng = engine.Engine(arch, synth.make_state_dict(arch), 2, 128, 128, use_graph=False)
+    x = synth.make_images(B, hw, hw, seed=21)
+    eng = engine.Engine(arch, synth.make_state_dict(arch), B, hw, hw, use_graph=False)
+    assert (hw == 512) == any(l.fn == "cp_head3x3_1x1_f32" for _, _, _, l in eng.launches)
     ref = [t.clone() for t in eng(x.cuda())]
     ref_dets = multi_pose_decode(ref[0], ref[1], ref[2], reg=ref[3], hm_hp=ref[4], hp_offset=ref[5], K=100)
     path, xin, outp = str(tmp_path / "p.cpplan"), str(tmp_path / "x.npy"), str(tmp_path / "out")
