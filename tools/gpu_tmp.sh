@@ -1,5 +1,14 @@
 #!/bin/bash
-timeout 300 python -m pytest tests/test_conv_hip.py -m gpu -q -x -k "head3x3 or winograd" 2>&1 | tail -4
-timeout 600 python -m pytest tests/test_engine_hip.py -m gpu -q -x -k "dla_34 or process or plan" 2>&1 | tail -4
-for f in 1 0; do CP_FUSE_HEADS=$f timeout 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys; l=json.loads(sys.stdin.read()); print('fuse=$f', l['value'], l['ms_per_step']); [print('   %-46s n=%2d %6.3f ms' % (k[:46], v['launches'], v['ms_per_step'])) for k,v in l['roofline']['kernels'].items() if 'vs64' in k or '256, 16' in k]"; done
+OUT=gpurun_out/r2m; mkdir -p $OUT
+tools/gpu_profile.sh r2m pmc > $OUT/profile.log 2>&1
+timeout 200 python tools/layer_profile.py res_50 16 > $OUT/layers_res50.txt 2>&1
+timeout 200 python tools/layer_profile.py hrnet 16 > $OUT/layers_hrnet.txt 2>&1
+cp $OUT/pmc_traffic.json profiles/r2_pmc_traffic.json
+timeout 300 python bench.py > $OUT/bench_default.json 2>/dev/null
+for cfg in "res_50 8" "res_50 16" "hrnet 8" "hrnet 16" "mobilenetv3 16" "shufflenetV2 16"; do set -- $cfg
+  timeout 200 python bench.py --arch $1 --batch $2 --no-cpu-baseline 2>/dev/null > $OUT/bench_$1_$2.json
+  python -c "
+import json; l=json.load(open('$OUT/bench_$1_$2.json')); r=l['roofline']; print('$1 B=$2', l['value'], 'img/s', l['ms_per_step'], 'ms; dom', r['kernel'][:40], r['frac'], 'all-mfma exe frac', r['all_mfma_kernels']['executed_frac'])"
+done
+python -c "
+import json; l=json.load(open('$OUT/bench_default.json')); print(l['value'], l['ms_per_step'], l['roofline']['kernel'], l['roofline']['frac'], l['roofline']['traffic'], l['cpu_baseline']['value'])"
