@@ -487,21 +487,37 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
     const int baseB = ((2 * tyy + rB) * WG_PWP + 2 * txx) * 4 + h * WGV_CG;
     const int offAe = baseA + fA * 4, offAo = baseA - fA * 4, offBe = baseB + fB * 4, offBo = baseB - fB * 4;
     wg_v2 vl[WGV_C / 8][4], vh[WGV_C / 8][4];
+    wg_v4 da[2][4], db[2][4];                               // raw patch rows, chunk kc + 1 in flight while chunk kc is transformed
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        da[0][j] = wg_lds4(smem + ((j & 1) ? offAo : offAe) + j * 4);
+        db[0][j] = wg_lds4(smem + ((j & 1) ? offBo : offBe) + j * 4);
+    }
 #pragma unroll
     for (int kc = 0; kc < WGV_C / 8; ++kc) {
-        const float* pc = smem + kc * 2 * WGV_CG;
+        if (kc + 1 < WGV_C / 8) {
+            const float* pc = smem + (kc + 1) * 2 * WGV_CG;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                da[(kc + 1) & 1][j] = wg_lds4(pc + ((j & 1) ? offAo : offAe) + j * 4);
+                db[(kc + 1) & 1][j] = wg_lds4(pc + ((j & 1) ? offBo : offBe) + j * 4);
+            }
+        }
         wg_v2 tl[4], th[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const wg_v4 da = wg_lds4(pc + ((j & 1) ? offAo : offAe) + j * 4);
-            const wg_v4 db = wg_lds4(pc + ((j & 1) ? offBo : offBe) + j * 4);
-            tl[j] = __builtin_elementwise_fma(sg, db.xy, da.xy);
-            th[j] = __builtin_elementwise_fma(sg, db.zw, da.zw);
+            tl[j] = __builtin_elementwise_fma(sg, db[kc & 1][j].xy, da[kc & 1][j].xy);
+            th[j] = __builtin_elementwise_fma(sg, db[kc & 1][j].zw, da[kc & 1][j].zw);
         }
         vl[kc][0] = tl[0] - tl[2]; vh[kc][0] = th[0] - th[2];
         vl[kc][1] = tl[1] + tl[2]; vh[kc][1] = th[1] + th[2];
         vl[kc][2] = tl[2] - tl[1]; vh[kc][2] = th[2] - th[1];
         vl[kc][3] = tl[1] - tl[3]; vh[kc][3] = th[1] - th[3];
+        // pin the chunk's transform HERE: the results are first used after the barrier below, so the compiler sank all 128
+        // transform instructions behind it and hoisted all 64 ds_read_b128 in front of it -- 256 VGPRs of raw patch in flight,
+        // 24 of them spilled to scratch (96 B per lane = 50 MB of HBM writes per launch, PMC WRITE_SIZE)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(vl[kc][j]), "+v"(vh[kc][j]));
     }
 
     __syncthreads();                // every wave has read its rows of the patch: the region becomes the reduction buffers
