@@ -171,7 +171,91 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
 #pragma unroll
         for (int w = 0; w < KW; ++w) ig_store_b<T>(Bs + w * T::B_FLOATS, tid, br[w]);
     };
-    if constexpr (PF == 2) {
+    if constexpr (PF == 3) {
+        // FULL-LINE gathers: 8 lanes per (pixel, corner) fetch 32 channels = one whole 128-byte line, for TWO k-steps at once
+        // (PF = 1 fetches the two 64-byte halves of a line one k-step apart; in between the five resident blocks push ~80 KB
+        // through the 32 KB L1, so the second half misses again: PMC 70 % L1 miss, every line moved L2 -> L1 twice).  The
+        // LDS footprint stays one k-step per buffer: all lanes blend once per pair, lanes q < 4 (channels 0..15 of the pair)
+        // hand their float4 to LDS for the even k-step, lanes q >= 4 keep theirs in registers one k-step longer.  The gathers
+        // of pair P+1 are issued from inside the even k-step of pair P and consumed after its odd k-step: 1.5 k-steps of
+        // MFMAs to land instead of half of one.  No VMEM instruction sits inside a conditional (see PF = 2).
+        static_assert(KW == 1 && BM % 32 == 0, "full-line gather: 16-channel k-steps, 32 pixels per pass");
+        constexpr int S3 = BM / 32;
+        const int q3 = tid & 7, p3 = tid >> 3, half3 = q3 >> 2;
+        float4 G0[S3], G1[S3], G2[S3], G3[S3], W3[S3], BL[S3], BR[T::B_SLOTS];
+        unsigned a00[S3], a01[S3], a10[S3], a11[S3];
+        int gtap = 0, gcl = 0;                                   // next 32-channel pair to gather (saturates at the end)
+        auto gather = [&]() __attribute__((always_inline)) {
+            if (gcl == 0) {                                      // LDS + VALU only
+#pragma unroll
+                for (int s2 = 0; s2 < S3; ++s2) {
+                    const int pl = p3 + s2 * 32;
+                    const int code = s_code[gtap * BM + pl];
+                    W3[s2] = s_w[gtap * BM + pl];
+                    a00[s2] = (unsigned)(code & 0x1FFFFFFF) * pixb + (unsigned)q3 * 16u;
+                    a01[s2] = a00[s2] + (((unsigned)code >> 29) & 1u) * pixb;
+                    a10[s2] = a00[s2] + (((unsigned)code >> 30) & 1u) * rowb;
+                    a11[s2] = a10[s2] + (a01[s2] - a00[s2]);
+                }
+            }
+            const char* xs = reinterpret_cast<const char*>(x) + (size_t)gcl * 4;      // uniform
+#pragma unroll
+            for (int s2 = 0; s2 < S3; ++s2) {
+                G0[s2] = ig_ldg4(reinterpret_cast<const float*>(xs + a00[s2]));
+                G1[s2] = ig_ldg4(reinterpret_cast<const float*>(xs + a01[s2]));
+                G2[s2] = ig_ldg4(reinterpret_cast<const float*>(xs + a10[s2]));
+                G3[s2] = ig_ldg4(reinterpret_cast<const float*>(xs + a11[s2]));
+            }
+            if (gtap * C + gcl + 2 * IG_BK < a.K) { gcl += 2 * IG_BK; if (gcl >= C) { gcl = 0; ++gtap; } }
+        };
+        auto blend = [&]() __attribute__((always_inline)) {
+#pragma unroll
+            for (int s2 = 0; s2 < S3; ++s2) {
+                const float4 w = W3[s2];
+                const dcn_v2 wx = {w.x, w.x}, wy = {w.y, w.y}, wz = {w.z, w.z}, ww = {w.w, w.w};
+                const dcn_v2 lo = __builtin_elementwise_fma(ww, (dcn_v2){G3[s2].x, G3[s2].y},
+                                  __builtin_elementwise_fma(wz, (dcn_v2){G2[s2].x, G2[s2].y},
+                                  __builtin_elementwise_fma(wy, (dcn_v2){G1[s2].x, G1[s2].y}, wx * (dcn_v2){G0[s2].x, G0[s2].y})));
+                const dcn_v2 hi = __builtin_elementwise_fma(ww, (dcn_v2){G3[s2].z, G3[s2].w},
+                                  __builtin_elementwise_fma(wz, (dcn_v2){G2[s2].z, G2[s2].w},
+                                  __builtin_elementwise_fma(wy, (dcn_v2){G1[s2].z, G1[s2].w}, wx * (dcn_v2){G0[s2].z, G0[s2].w})));
+                BL[s2] = make_float4(lo.x, lo.y, hi.x, hi.y);
+            }
+        };
+        auto hand_over = [&](int half, float* As, float* Bs) __attribute__((always_inline)) {
+            if (half3 == half) {
+#pragma unroll
+                for (int s2 = 0; s2 < S3; ++s2)
+                    *reinterpret_cast<float4*>(As + (p3 + s2 * 32) * IG_LDK + (q3 & 3) * 4) = BL[s2];
+            }
+            ig_store_b<T>(Bs, tid, BR);
+        };
+        float* As1 = As0 + T::A_FLOATS; float* Bs1 = Bs0 + T::B_FLOATS;
+        ig_load_b<T>(a, 0, n0, tid, BR);
+        gather();
+        blend();
+        hand_over(0, As0, Bs0);
+        __syncthreads();
+#pragma unroll 1
+        for (int ks = 0; ks < nk; ks += 2) {
+            // even k-step: the weight slice first (vmcnt retires in order: the hand-over below then waits for it with the
+            // eight gathers still in flight), then the next pair's gathers
+            ig_compute<T, MF>(As0, Bs0, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
+                ig_load_b<T>(a, (ks + 1 < nk ? ks + 1 : nk - 1) * IG_BK, n0, tid, BR);
+                gather();
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            hand_over(1, As1, Bs1);
+            __syncthreads();
+            ig_compute<T, MF>(As1, Bs1, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
+                ig_load_b<T>(a, (ks + 2 < nk ? ks + 2 : nk - 1) * IG_BK, n0, tid, BR);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            blend();
+            hand_over(0, As0, Bs0);
+            __syncthreads();
+        }
+    } else if constexpr (PF == 2) {
         static_assert(KW == 1, "two-deep prefetch is built for 16-channel k-steps");
         float4 C0[2][ASL], C1[2][ASL], C2[2][ASL], C3[2][ASL], W[2][ASL], BR[2][T::B_SLOTS];
         int ltap = 0, lcl = 0;                                   // position of the next k-step to gather (saturates at the end)
@@ -348,6 +432,7 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
         case 5064064: rc = launch_dcn<64, 64, 2, 2, 32, 1, 2>(a, s); break;     // two-deep gather prefetch
         case 5064128: rc = (d->ldw % 128 == 0) ? launch_dcn<64, 128, 2, 2, 32, 1, 2>(a, s) : launch_dcn<64, 64, 2, 2, 32, 1, 2>(a, s); break;
         case 5128064: rc = launch_dcn<128, 64, 2, 2, 32, 1, 2>(a, s); break;
+        case 7064064: rc = (d->C % 32 == 0) ? launch_dcn<64, 64, 2, 2, 32, 1, 3>(a, s) : launch_dcn<64, 64, 2, 2, 32>(a, s); break;   // full-line gathers
         default: CP_CHECK_ARG(false, "dcn_v2: unsupported tile %d (ldw=%d)", tile, d->ldw);
     }
     if (rc) return rc;

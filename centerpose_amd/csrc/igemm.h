@@ -128,7 +128,7 @@ __device__ __forceinline__ void ig_load_b(const ConvArgs& a, int k0, int n0, int
 #pragma unroll
     for (int s = 0; s < T::B_SLOTS; ++s) {
         const int idx = tid + s * IG_THREADS;
-        if (idx < T::B_F4) br[s] = *reinterpret_cast<const float4*>(w + (size_t)(n0 + (idx >> 2)) * a.K + k0 + (idx & 3) * 4);
+        if (T::B_F4 % IG_THREADS == 0 || idx < T::B_F4) br[s] = *reinterpret_cast<const float4*>(w + (size_t)(n0 + (idx >> 2)) * a.K + k0 + (idx & 3) * 4);
     }
 }
 template <class T>
@@ -137,7 +137,7 @@ __device__ __forceinline__ void ig_store_b(float* Bs, int tid, const float4 (&br
 #pragma unroll
     for (int s = 0; s < T::B_SLOTS; ++s) {
         const int idx = tid + s * IG_THREADS;
-        if (idx < T::B_F4) *reinterpret_cast<float4*>(Bs + (idx >> 2) * IG_LDK + (idx & 3) * 4) = br[s];
+        if (T::B_F4 % IG_THREADS == 0 || idx < T::B_F4) *reinterpret_cast<float4*>(Bs + (idx >> 2) * IG_LDK + (idx & 3) * 4) = br[s];
     }
 }
 

@@ -253,7 +253,10 @@ def _dcn_case(seed, B, C, Co, H, W, big_offsets):
                                                (64, 64, 11, 13, True, 2064064), (32, 128, 9, 16, False, 2128064),
                                                # two-deep gather prefetch (PF = 2): even / odd k-step counts, ragged M, 64x128 tile
                                                (64, 64, 11, 13, True, 5064064), (16, 64, 9, 7, True, 5064064), (48, 128, 6, 10, True, 5064128),
-                                               (128, 256, 8, 8, False, 5064128), (32, 64, 12, 12, True, 5128064)])
+                                               (128, 256, 8, 8, False, 5064128), (32, 64, 12, 12, True, 5128064),
+                                               # full-line gathers (PF = 3): 32 channels per pair of k-steps, ragged M, falls back for C % 32 != 0
+                                               (64, 64, 11, 13, True, 7064064), (32, 64, 9, 7, True, 7064064), (96, 128, 6, 10, True, 7064064),
+                                               (128, 256, 8, 8, False, 7064064), (48, 64, 5, 9, True, 7064064)])
 def test_dcn_v2_vs_scalar_oracle(C, Co, H, W, big, tile):
     from centerpose_amd import ops
     from oracle import dcn as odcn
