@@ -38,9 +38,10 @@ enum { FN_CONV = 1, FN_WINO = 2, FN_DCN = 3, FN_STEM7 = 4, FN_POOL = 5, FN_UPADD
 enum { REF_NULL = 0, REF_BUF = 1, REF_CONST = 2 };
 
 struct Op {
-    uint32_t fn = 0, out_index = 0;
+    uint32_t fn = 0, out_index = 0, stream = 0;      // stream: 0 main / 1 side capture stream (plan.py: Engine.schedule)
     std::vector<unsigned char> desc;
     std::vector<float*> ptrs;
+    std::vector<int> bufid;                         // activation-buffer id behind each pointer, -1 for constants / NULL
     std::vector<int> ints;
 };
 
@@ -57,7 +58,7 @@ struct cp_plan {
     bool use_graph = false, warmed = false;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    hipStream_t cap_stream = nullptr;
+    hipStream_t cap_stream = nullptr, side_stream = nullptr;
     // decode workspace of cp_plan_process (allocated on first use)
     float* ws_scores = nullptr;
     int* ws_inds = nullptr;
@@ -146,12 +147,59 @@ int run_all(cp_plan* pl, hipStream_t s)
     return 0;
 }
 
+// The schedule on two capture streams, as engine.Engine._run_branches enqueues it: every op goes to the stream the plan
+// names; an op follows the last writer of each buffer it reads and the last writer / the readers of the buffer it writes
+// (RAW / WAW / WAR per activation buffer, derived here from the refs); edges that cross streams become event waits, which
+// the capture turns into graph edges.  Streams are FIFO, so per stream only the youngest awaited op matters.
+int run_two_streams(cp_plan* pl, hipStream_t main, hipStream_t side, std::vector<hipEvent_t>& ev)
+{
+    const size_t n = pl->ops.size(), nb = pl->bufs.size();
+    std::vector<int> last_writer(nb, -1);
+    std::vector<std::vector<int>> readers(nb);
+    hipStream_t st[2] = {main, side};
+    int waited[2] = {-1, -1}, tail[2] = {-1, -1};
+    ev.assign(n + 1, nullptr);
+    if (hipEventCreateWithFlags(&ev[n], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[n], main) != hipSuccess ||
+        hipStreamWaitEvent(side, ev[n], 0) != hipSuccess) { cp_set_error("plan: fork of the side stream failed"); return 2; }
+    for (size_t i = 0; i < n; ++i) {
+        const Op& o = pl->ops[i];
+        const int me = o.stream ? 1 : 0, other = me ^ 1;
+        int need = -1;                                   // youngest op of the other stream this one must follow
+        auto follow = [&](int j) { if (j >= 0 && (pl->ops[j].stream ? 1 : 0) == other && j > need) need = j; };
+        for (size_t k = 0; k < o.ptrs.size(); ++k) {
+            const int b = o.bufid[k];
+            if (b < 0) continue;
+            follow(last_writer[b]);
+            if (k == o.out_index) for (int j : readers[b]) follow(j);
+        }
+        if (need > waited[me]) {
+            if (hipStreamWaitEvent(st[me], ev[need], 0) != hipSuccess) { cp_set_error("plan: event wait failed"); return 2; }
+            waited[me] = need;
+        }
+        if (int rc = run_op(o, st[me])) return rc;
+        if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[i], st[me]) != hipSuccess) {
+            cp_set_error("plan: event record failed");
+            return 2;
+        }
+        tail[me] = (int)i;
+        for (size_t k = 0; k < o.ptrs.size(); ++k) {
+            const int b = o.bufid[k];
+            if (b < 0) continue;
+            if (k == o.out_index) { last_writer[b] = (int)i; readers[b].clear(); }
+            else readers[b].push_back((int)i);
+        }
+    }
+    if (tail[1] >= 0 && hipStreamWaitEvent(main, ev[tail[1]], 0) != hipSuccess) { cp_set_error("plan: join of the side stream failed"); return 2; }
+    return 0;
+}
+
 void free_plan(cp_plan* pl)
 {
     if (!pl) return;
     if (pl->exec) (void)hipGraphExecDestroy(pl->exec);
     if (pl->graph) (void)hipGraphDestroy(pl->graph);
     if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
+    if (pl->side_stream) (void)hipStreamDestroy(pl->side_stream);
     for (float* p : pl->bufs) if (p) (void)hipFree(p);
     for (float* p : pl->consts) if (p) (void)hipFree(p);
     if (pl->ws_scores) (void)hipFree(pl->ws_scores);
@@ -173,7 +221,8 @@ extern "C" int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_
     CP_CHECK_ARG(blob && out, "plan_create: null pointer");
     *out = nullptr;
     Reader r{static_cast<const unsigned char*>(blob), bytes};
-    CP_CHECK_ARG(bytes >= 48 && memcmp(blob, "CPPLAN02", 8) == 0, "plan_create: not a centerpose_amd plan (bad magic)");
+    CP_CHECK_ARG(bytes >= 48 && (memcmp(blob, "CPPLAN03", 8) == 0 || memcmp(blob, "CPPLAN02", 8) == 0),
+                 "plan_create: not a centerpose_amd plan (bad magic)");
     r.p = 8;
     const uint32_t abi = r.u32(), B = r.u32(), H = r.u32(), W = r.u32(), nbuf = r.u32(), nconst = r.u32(), nops = r.u32(),
                    nout = r.u32(), mlen = r.u32();
@@ -207,9 +256,11 @@ extern "C" int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_
             PLAN_FAIL("plan_create: upload of constant %u failed", i);
     }
     bool bad_ref = false;
+    int last_buf = -1;                                  // buffer id of the reference resolved last (-1: constant / NULL)
     auto resolve = [&](Reader& rd) -> float* {
         Ref f;
         f.kind = rd.u32(); f.id = rd.u32(); f.off = rd.u64(); f.numel = rd.u64();
+        last_buf = (f.kind == REF_BUF && f.id < nbuf) ? (int)f.id : -1;
         if (f.kind == REF_NULL) return nullptr;
         if (f.kind == REF_BUF && f.id < nbuf && f.off < buf_numel[f.id] && f.numel <= buf_numel[f.id] - f.off) return pl->bufs[f.id] + f.off;
         if (f.kind == REF_CONST && f.id < nconst && f.numel <= ci[f.id].numel) return pl->consts[f.id];
@@ -230,12 +281,12 @@ extern "C" int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_
         o.fn = r.u32();
         const uint32_t dlen = r.u32(), nptr = r.u32(), nint = r.u32();
         o.out_index = r.u32();
-        (void)r.u32();
-        if (dlen > 4096 || nptr > 64 || nint > 64) { r.ok = false; break; }
+        o.stream = r.u32();
+        if (dlen > 4096 || nptr > 64 || nint > 64 || o.stream > 1 || o.out_index >= nptr) { r.ok = false; break; }
         o.desc.resize(dlen);
         if (dlen) r.take(o.desc.data(), dlen);
         r.skip_pad8();
-        for (uint32_t k = 0; k < nptr; ++k) o.ptrs.push_back(resolve(r));
+        for (uint32_t k = 0; k < nptr; ++k) { o.ptrs.push_back(resolve(r)); o.bufid.push_back(last_buf); }
         o.ints.resize(nint);
         if (nint) r.take(o.ints.data(), 4 * (size_t)nint);
         r.skip_pad8();
@@ -297,9 +348,14 @@ extern "C" int cp_plan_forward(cp_plan* pl, const float* images, void* stream)
         if (int rc = run_all(pl, s)) return rc;
         if (hipStreamSynchronize(s) != hipSuccess) { cp_set_error("plan_forward: warm-up pass failed"); return 2; }
         if (hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) != hipSuccess) { cp_set_error("plan_forward: stream create"); return 2; }
+        bool two = false;
+        for (const Op& o : pl->ops) two = two || o.stream != 0;
+        if (two && hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking) != hipSuccess) { cp_set_error("plan_forward: stream create"); return 2; }
         if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { cp_set_error("plan_forward: begin capture"); return 2; }
-        const int rc = run_all(pl, pl->cap_stream);
+        std::vector<hipEvent_t> ev;
+        const int rc = two ? run_two_streams(pl, pl->cap_stream, pl->side_stream, ev) : run_all(pl, pl->cap_stream);
         hipError_t e = hipStreamEndCapture(pl->cap_stream, &pl->graph);
+        for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
         if (rc) return rc;
         if (e != hipSuccess || !pl->graph) { cp_set_error("plan_forward: end capture: %s", hipGetErrorString(e)); return 2; }
         e = hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0);

@@ -397,7 +397,51 @@ class Engine:
             deps.append(sorted(d))
         return deps
 
-    def _run_branches(self, main, nstreams, deps):
+    def schedule(self, durations=None, nstreams=2):
+        """Re-order the launch list for `nstreams` capture streams: classic list scheduling on the data-dependency DAG
+        (`dependencies()`), priority = longest remaining path (b-level) under the measured per-launch durations.  The
+        emission order follows the reference's forward(), which walks one branch after the other (DLAUp: ida_0, ida_1, ...;
+        HRNet: branch by branch); the greedy placement of `_run_branches` can only overlap what happens to be adjacent in
+        that order.  Scheduling by critical path puts the independent IDAUp projections / HRNet branches next to the
+        under-filled small-map launches: dla_34 B=16 8.19 -> 7.97 ms, hrnet B=8 6.96 -> 6.27 ms per forward, outputs
+        bit-identical (tools/sched_try.py).  Any result is a topological order of the same DAG, so eager execution of
+        the re-ordered list computes the same values.  Sets `self.launches` (new order) and `self.stream_plan`."""
+        n = len(self.launches)
+        if durations is None:
+            durations = [r["ms"] for r in self.profile_in_sequence(iters=3)]
+        deps = self.dependencies()
+        children = [[] for _ in range(n)]
+        for i, d in enumerate(deps):
+            for j in d:
+                children[j].append(i)
+        blevel = [0.0] * n
+        for i in reversed(range(n)):
+            blevel[i] = durations[i] + max([blevel[c] for c in children[i]], default=0.0)
+        indeg = [len(d) for d in deps]
+        ready = [i for i in range(n) if indeg[i] == 0]
+        free = [0.0] * nstreams
+        start, finish, assign = [0.0] * n, [0.0] * n, [0] * n
+        for _ in range(n):
+            best = None
+            for i in ready:
+                est = max([finish[j] for j in deps[i]], default=0.0)
+                for p in range(nstreams):
+                    key = (max(est, free[p]), -blevel[i], p)
+                    if best is None or key < best[0]:
+                        best = (key, i, p)
+            (t, _, _), i, p = best
+            ready.remove(i)
+            start[i], finish[i], free[p], assign[i] = t, t + durations[i], t + durations[i], p
+            for c in children[i]:
+                indeg[c] -= 1
+                if indeg[c] == 0:
+                    ready.append(c)
+        order = sorted(range(n), key=lambda i: (start[i], i))     # a child never starts before its parents have finished
+        self.launches = [self.launches[i] for i in order]
+        self.stream_plan = [assign[i] for i in order]
+        return max(finish)
+
+    def _run_branches(self, main, nstreams, deps, assign=None):
         """Enqueue the schedule on `nstreams` streams (main + side streams): independent branches of the graph
         (HRNet's parallel resolutions, IDAUp projections) go to different streams with event edges for the real data
         dependencies.  Under hipGraph capture the events become graph edges; small launches that cannot fill 256 CUs
@@ -415,8 +459,8 @@ class Engine:
         waited = [[-1] * len(streams) for _ in streams]      # waited[s][t]: youngest launch of stream t that s has waited for
         for i, (_, _, _, launch) in enumerate(self.launches):
             # continue the chain of a predecessor that is still the tail of its stream; otherwise take an idle stream
-            sidx = None
-            for j in sorted(deps[i], reverse=True):
+            sidx = assign[i] if assign is not None else None      # explicit placement (tools/sched_try.py)
+            for j in (sorted(deps[i], reverse=True) if sidx is None else ()):
                 if tail[where[j]] == j:
                     sidx = where[j]
                     break
@@ -508,11 +552,13 @@ class Engine:
             self.stream_of_launch = [0] * len(self.launches)
             return
         if nstreams > 1:
+            if getattr(self, "stream_plan", None) is None and nstreams == 2 and os.environ.get("CP_SCHED", "1") != "0":
+                self.schedule()
             deps = self.dependencies()
             try:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
-                    self._run_branches(s, nstreams, deps)
+                    self._run_branches(s, nstreams, deps, getattr(self, "stream_plan", None))
             except RuntimeError:                 # a failed multi-stream capture must not take the engine down
                 g = None
                 self._capture_refs = None

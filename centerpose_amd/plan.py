@@ -11,7 +11,7 @@ they name -- in a flat little-endian binary layout with no pickled objects, so t
 
 Layout (all integers little-endian; offsets in bytes from the start of the file):
 
-    char[8]  magic "CPPLAN02"
+    char[8]  magic "CPPLAN03"  ("CPPLAN02" files are still read: the same layout with stream = 0 in every op)
     u32      abi            cp_abi_version() of the library that wrote it (descriptor struct layouts)
     u32      B, H, W        network input [B,3,H,W]
     u32      nbuf, nconst, nops, nout
@@ -22,8 +22,11 @@ Layout (all integers little-endian; offsets in bytes from the start of the file)
     {u64 numel, u64 offset}[nconst]      packed weights, folded scale/shift, Winograd U: raw float32 at `offset`
     ref                     network input
     {ref, u32[4] shape}[nout]            head outputs (NCHW)
-    op[nops]:  u32 fn, u32 desc_bytes, u32 nptr, u32 nint, u32 out_index, u32 0,
+    op[nops]:  u32 fn, u32 desc_bytes, u32 nptr, u32 nint, u32 out_index, u32 stream,
                u8[desc_bytes] zero padded to 8, ref[nptr], i32[nint] zero padded to 8
+               ops are stored in EXECUTION order (engine.Engine.schedule: critical-path list schedule for two capture
+               streams); `stream` = 0 main / 1 side.  A reader derives the cross-stream edges from the refs (an op follows
+               the last writer of every buffer it reads, and the last writer and readers of the buffer it writes).
     ... constant data, each block 64-byte aligned
     ref = {u32 kind (0 NULL, 1 buffer, 2 constant), u32 id, u64 offset (floats), u64 numel}
 """
@@ -36,7 +39,8 @@ import torch
 
 from . import _lib, ops
 
-MAGIC = b"CPPLAN02"
+MAGIC = b"CPPLAN03"
+MAGIC_V2 = b"CPPLAN02"
 REF_NULL, REF_BUF, REF_CONST = 0, 1, 2
 FN_NAMES = {v: k for k, v in ops.FN_IDS.items()}
 DESC_TYPES = {"cp_conv2d_f32": ops.ConvDesc, "cp_conv3x3_winograd_f32": ops.ConvDesc, "cp_dcn_v2_f32": ops.DcnDesc,
@@ -83,17 +87,19 @@ def _pack_ref(r):
     return struct.pack("<IIQQ", *r)
 
 
-def serialize(launches, meta, inp, outputs, abi):
-    """launches: [(kind, name, flops, ops.Launch)] -> bytes of a plan file."""
+def serialize(launches, meta, inp, outputs, abi, streams=None):
+    """launches: [(kind, name, flops, ops.Launch)] in execution order, streams: capture stream per launch -> bytes of a plan file."""
+    streams = list(streams) if streams is not None else [0] * len(launches)
+    assert len(streams) == len(launches) and all(x in (0, 1) for x in streams)
     written = {_storage_key(inp)} | {_storage_key(l.out) for _, _, _, l in launches}
     enc = _Encoder(written)
     in_ref = enc.ref(inp)
     op_blobs = []
-    for _, _, _, l in launches:
+    for (_, _, _, l), st in zip(launches, streams):
         desc = bytes(l.desc) if l.desc is not None else b""
         refs = b"".join(_pack_ref(enc.ref(t)) for t in l.tensors)
         ints = _pad8(struct.pack("<%di" % len(l.ints), *l.ints))
-        op_blobs.append(struct.pack("<IIIIII", ops.FN_IDS[l.fn], len(desc), len(l.tensors), len(l.ints), l.out_index, 0)
+        op_blobs.append(struct.pack("<IIIIII", ops.FN_IDS[l.fn], len(desc), len(l.tensors), len(l.ints), l.out_index, st)
                         + _pad8(desc) + refs + ints)
     out_blob = b"".join(_pack_ref(enc.ref(o)) + struct.pack("<4I", *o.shape) for o in outputs)
     mj = dict(meta)
@@ -119,9 +125,14 @@ def serialize(launches, meta, inp, outputs, abi):
 
 
 def save_plan(engine, path):
-    """Write `engine`'s compiled plan (packed constants + launch schedule) to `path`."""
+    """Write `engine`'s compiled plan (packed constants + launch schedule) to `path`.  The schedule is the two-stream one
+    (`Engine.schedule`, measured once here if the engine has not captured yet), so the C runtime replays what Python replays."""
+    import os
+    if getattr(engine, "stream_plan", None) is None and os.environ.get("CP_SCHED", "1") != "0" and os.environ.get("CP_STREAMS", "2") == "2":
+        engine.schedule()
     meta = {"arch": engine.arch, "flops_per_image": int(engine.flops_per_image)}
-    blob = serialize(engine.launches, meta, engine.input, engine.outputs, int(_lib.lib().cp_abi_version()))
+    blob = serialize(engine.launches, meta, engine.input, engine.outputs, int(_lib.lib().cp_abi_version()),
+                     getattr(engine, "stream_plan", None))
     with open(path, "wb") as f:
         f.write(blob)
     return len(blob)
@@ -147,8 +158,8 @@ class _Reader:
 
 def parse(blob):
     """bytes -> dict(abi, B, H, W, meta, buffers, consts [(numel, offset)], input ref, outputs [(ref, shape)],
-    ops [(fn name, desc bytes, refs, ints, out_index)]).  Host only; validates structure, raises ValueError."""
-    if len(blob) < 48 or bytes(blob[:8]) != MAGIC:
+    ops [(fn name, desc bytes, refs, ints, out_index, stream)]).  Host only; validates structure, raises ValueError."""
+    if len(blob) < 48 or bytes(blob[:8]) not in (MAGIC, MAGIC_V2):
         raise ValueError("not a centerpose_amd plan file (magic %r)" % bytes(blob[:8]))
     r = _Reader(blob)
     r.p = 8
@@ -176,7 +187,9 @@ def parse(blob):
     outputs = [(check_ref(r.ref()), r.take("<4I")) for _ in range(nout)]
     plan_ops = []
     for _ in range(nops):
-        fn, dlen, nptr, nint, oi, _ = r.take("<IIIIII")
+        fn, dlen, nptr, nint, oi, st = r.take("<IIIIII")
+        if st > 1:
+            raise ValueError("plan file: op on stream %d (0 or 1 expected)" % st)
         if fn not in FN_NAMES:
             raise ValueError("plan file: unknown launch function id %d" % fn)
         name = FN_NAMES[fn]
@@ -187,7 +200,7 @@ def parse(blob):
         refs = [check_ref(r.ref()) for _ in range(nptr)]
         ints = list(r.take("<%di" % nint))
         r.p += (-4 * nint) % 8
-        plan_ops.append((name, desc, refs, ints, oi))
+        plan_ops.append((name, desc, refs, ints, oi, st))
     if len(meta.get("ops", ())) != nops:
         raise ValueError("plan file: meta lists %d ops, schedule has %d" % (len(meta.get("ops", ())), nops))
     return dict(abi=abi, B=B, H=H, W=W, meta=meta, buffers=buffers, consts=consts, input=inp, outputs=outputs, ops=plan_ops)
@@ -214,7 +227,7 @@ def load_plan(path, device="cuda", use_graph=True):
                 return None
             return bufs[i][off:off + n] if kind == REF_BUF else consts[i]
         launches = []
-        for (name, desc, refs, ints, oi), m in zip(p["ops"], p["meta"]["ops"]):
+        for (name, desc, refs, ints, oi, _), m in zip(p["ops"], p["meta"]["ops"]):
             d = DESC_TYPES[name].from_buffer_copy(desc) if name in DESC_TYPES else None
             launches.append((m["kind"], m["name"], m["flops"], ops.Launch(name, d, [view(r) for r in refs], ints, oi)))
         eng = Engine.__new__(Engine)
@@ -228,4 +241,6 @@ def load_plan(path, device="cuda", use_graph=True):
         eng.activation_bytes = 4 * sum(p["buffers"])
         eng.graph = None
         eng.use_graph = use_graph
+        streams = [o[5] for o in p["ops"]]
+        eng.stream_plan = streams if any(streams) else None       # a file without a schedule: capture() makes one
     return eng

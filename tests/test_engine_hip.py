@@ -191,6 +191,8 @@ def test_c_plan_handle_runs_network_without_engine(arch, B, hw, tmp_path):
     ref_dets = multi_pose_decode(ref[0], ref[1], ref[2], reg=ref[3], hm_hp=ref[4], hp_offset=ref[5], K=100)
     path, xin, outp = str(tmp_path / "p.cpplan"), str(tmp_path / "x.npy"), str(tmp_path / "out")
     eng.save_plan(path)
+    assert eng.stream_plan is not None and 1 in eng.stream_plan          # the file carries the two-stream schedule
+    ref = [t.clone() for t in eng(x.cuda())]                              # ... and the engine still computes the same bits in that order
     np.save(xin, x.numpy())
     r = subprocess.run([sys.executable, "-c", C_PLAN_CHILD, root, path, xin, outp], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -258,6 +260,43 @@ def test_multistream_capture_is_bit_identical(arch):
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert all(torch.equal(p, q) for p, q in zip(outs[0], o))
+
+
+@pytest.mark.parametrize("arch", ["dla_34", "hrnet", "shufflenetV2"])
+def test_critical_path_schedule(arch, monkeypatch, tmp_path):
+    """Engine.schedule: the launch list re-ordered by critical path for two capture streams is a permutation of the emission
+    order that respects every data dependency, uses both streams, replays to the same bits as the emission-order capture, and
+    travels in the plan file (ops in execution order + stream per op) to `Engine.from_plan`."""
+    from centerpose_amd import engine, plan, synth
+    sd = synth.make_state_dict(arch)
+    x = synth.make_images(2, 128, 128, seed=5).cuda()
+    monkeypatch.setenv("CP_SCHED", "0")
+    e0 = engine.Engine(arch, sd, 2, 128, 128, use_graph=True)
+    for _ in range(2):
+        ref = [t.clone() for t in e0(x)]
+    assert getattr(e0, "stream_plan", None) is None
+    names0 = [n for _, n, _, _ in e0.launches]
+    monkeypatch.setenv("CP_SCHED", "1")
+    e1 = engine.Engine(arch, sd, 2, 128, 128, use_graph=True)
+    for _ in range(3):
+        out = [t.clone() for t in e1(x)]
+    names1 = [n for _, n, _, _ in e1.launches]
+    assert sorted(names0) == sorted(names1) and len(e1.stream_plan) == len(names1) and set(e1.stream_plan) == {0, 1}
+    assert e1.stream_of_launch == e1.stream_plan
+    deps = e1.dependencies()
+    assert all(all(j < i for j in d) for i, d in enumerate(deps))
+    assert all(torch.equal(p, q) for p, q in zip(ref, out))
+    assert all(torch.equal(p, q) for p, q in zip(ref, (e1.run_eager(), e1.outputs)[1]))      # the new order, eagerly
+    path = str(tmp_path / "s.cpplan")
+    e1.save_plan(path)
+    p = plan.parse(memoryview(np.fromfile(path, dtype=np.uint8)))
+    assert [o[5] for o in p["ops"]] == e1.stream_plan and [m["name"] for m in p["meta"]["ops"]] == names1
+    e2 = engine.Engine.from_plan(path)
+    assert e2.stream_plan == e1.stream_plan
+    for _ in range(2):
+        out2 = e2(x)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(ref, out2))
 
 
 def test_dag_graph_is_bit_identical(monkeypatch):

@@ -173,6 +173,17 @@ def test_plan_format_serialize_parse_and_schema():
     assert len(p["consts"]) == 4
     d = ops.ConvDesc.from_buffer_copy(p["ops"][2][1])
     assert (d.kh, d.Cout, d.outNCHW, d.act) == (1, 1, 1, ops.ACT_SIGMOID)
+    # execution streams: default all on the main stream; a schedule is stored per op; format 02 files (no schedule) still parse
+    assert blob[:8] == b"CPPLAN03" and [o[5] for o in p["ops"]] == [0, 0, 0]
+    blob2 = plan.serialize([("conv", "a", 10, l1), ("pool", "p", 0, l2), ("conv", "h", 5, l3)],
+                           {"arch": "x", "flops_per_image": 3}, inp, [out], 2, streams=[0, 1, 0])
+    assert [o[5] for o in plan.parse(memoryview(blob2))["ops"]] == [0, 1, 0] and len(blob2) == len(blob)
+    assert [o[:5] for o in plan.parse(memoryview(b"CPPLAN02" + blob[8:]))["ops"]] == [o[:5] for o in p["ops"]]
+    with pytest.raises(ValueError):                             # a third stream does not exist
+        bad = bytearray(blob2)
+        pos = blob2.index(struct.pack("<IIIIII", ops.FN_IDS["cp_maxpool2d_nhwc_f32"], 0, 2, 9, l2.out_index, 1))
+        bad[pos + 20:pos + 24] = struct.pack("<I", 2)
+        plan.parse(memoryview(bytes(bad)))
     with pytest.raises(ValueError):
         plan.parse(memoryview(b"NOTAPLAN" + blob[8:]))
     with pytest.raises(ValueError):                             # unknown launch function id
