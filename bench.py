@@ -180,7 +180,9 @@ def main():
 
     B = args.batch
     sd = synth.make_state_dict(args.arch)
-    eng = engine.Engine(args.arch, sd, B, 512, 512, device=dev, use_graph=not args.no_graph)
+    # the decode is part of the engine's schedule (decode_k): forward + sigmoid + decode = ONE hipGraph replay per step, the
+    # peak extraction overlapping the last head convolutions on the second capture stream
+    eng = engine.Engine(args.arch, sd, B, 512, 512, device=dev, use_graph=not args.no_graph, decode_k=100)
     lo, _ = cpd.shard_range(B * world, rank, world)
     images = synth.make_images(B, seed=317 + lo).to(dev)      # this rank's shard, resident in HBM
     eng.input.copy_(images)
@@ -189,10 +191,9 @@ def main():
     def step():
         """one batch through backbone + heads + decode; the all-gather of its detections is left running on the side
         stream and collected one step later (the first call returns None)."""
-        hm, wh, hps, reg, hm_hp, hp_offset = eng(eng.input)
-        dets = multi_pose_decode(hm, wh, hps, reg=reg, hm_hp=hm_hp, hp_offset=hp_offset, K=100)
+        _, dets = eng.process(eng.input)
         prev = gat.collect() if gat.pending else None
-        gat.submit(dets)
+        gat.submit(dets.clone())         # eng.dets is a static buffer: the exchange / the caller get their own copy
         return prev
 
     for _ in range(args.warmup):

@@ -277,12 +277,13 @@ extern "C" int cp_decode_workspace_bytes(int B, int J, int K, size_t* scores_byt
     return 0;
 }
 
-extern "C" int cp_multi_pose_decode_f32(const float* heat, const float* wh, const float* kps,
-                                        const float* reg, const float* hm_hp, const float* hp_offset,
-                                        int B, int cat, int J, int H, int W, int K, float* dets,
-                                        float* ws_scores, int* ws_inds, void* stream)
+// The decode in two halves, so that a launch schedule (engine.Engine / the plan runtime) can put them into its graph as two
+// nodes: the peak extraction needs only hm and hm_hp and overlaps the remaining head convolutions on the other capture stream;
+// the assignment needs all six heads.  cp_multi_pose_decode_f32 = both, back to back.
+extern "C" int cp_decode_topk_f32(const float* heat, const float* hm_hp, int B, int cat, int J, int H, int W, int K,
+                                  float* ws_scores, int* ws_inds, void* stream)
 {
-    CP_CHECK_ARG(heat && wh && kps && dets && ws_scores && ws_inds, "multi_pose_decode: null pointer");
+    CP_CHECK_ARG(heat && ws_scores && ws_inds, "multi_pose_decode: null pointer");
     CP_CHECK_ARG(hm_hp != nullptr,
                  "multi_pose_decode: hm_hp is required (the reference raises NameError without it, decode.py:307)");
     CP_CHECK_ARG(B > 0 && cat > 0 && J > 0 && H > 0 && W > 0, "multi_pose_decode: bad shape");
@@ -312,8 +313,29 @@ extern "C" int cp_multi_pose_decode_f32(const float* heat, const float* wh, cons
     else hipLaunchKernelGGL(nms_topk_kernel<false>, dim3(B * (1 + J)), dim3(TK_THREADS), lds, s, heat, hm_hp, cat, J, H, W, K, P,
                             nmax, chunk, ws_scores, ws_inds);
     CP_CHECK_LAUNCH("nms_topk_kernel");
-    hipLaunchKernelGGL(pose_assign_kernel, dim3(B * J), dim3(128), 0, s, wh, kps, reg, hp_offset, ws_scores, ws_inds, J,
+    cp_note_kernel(ck ? "nms_topk_kernel<true>" : "nms_topk_kernel<false>");
+    return 0;
+}
+
+extern "C" int cp_decode_assign_f32(const float* wh, const float* kps, const float* reg, const float* hp_offset,
+                                    const float* ws_scores, const int* ws_inds, int B, int J, int H, int W, int K, float* dets,
+                                    void* stream)
+{
+    CP_CHECK_ARG(wh && kps && dets && ws_scores && ws_inds, "multi_pose_decode: null pointer");
+    CP_CHECK_ARG(B > 0 && J > 0 && H > 0 && W > 0 && K > 0 && K <= TK_MAX_K, "multi_pose_decode: bad shape");
+    hipLaunchKernelGGL(pose_assign_kernel, dim3(B * J), dim3(128), 0, (hipStream_t)stream, wh, kps, reg, hp_offset, ws_scores, ws_inds, J,
                        H, W, K, dets);
     CP_CHECK_LAUNCH("pose_assign_kernel");
+    cp_note_kernel("pose_assign_kernel");
     return 0;
+}
+
+extern "C" int cp_multi_pose_decode_f32(const float* heat, const float* wh, const float* kps,
+                                        const float* reg, const float* hm_hp, const float* hp_offset,
+                                        int B, int cat, int J, int H, int W, int K, float* dets,
+                                        float* ws_scores, int* ws_inds, void* stream)
+{
+    CP_CHECK_ARG(heat && wh && kps && dets && ws_scores && ws_inds, "multi_pose_decode: null pointer");
+    if (int rc = cp_decode_topk_f32(heat, hm_hp, B, cat, J, H, W, K, ws_scores, ws_inds, stream)) return rc;
+    return cp_decode_assign_f32(wh, kps, reg, hp_offset, ws_scores, ws_inds, B, J, H, W, K, dets, stream);
 }

@@ -29,12 +29,15 @@ int cp_scale_add_nhwc_f32(const float*, int, const float*, int, const float*, in
 int cp_shuffle_concat_nhwc_f32(const float*, int, const float*, int, float*, int, long long, int, int, void*);
 int cp_multi_pose_decode_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int,
                              int, int, float*, float*, int*, void*);
+int cp_decode_topk_f32(const float*, const float*, int, int, int, int, int, int, float*, int*, void*);
+int cp_decode_assign_f32(const float*, const float*, const float*, const float*, const float*, const int*, int, int, int, int, int, float*,
+                         void*);
 }
 
 namespace {
 
 enum { FN_CONV = 1, FN_WINO = 2, FN_DCN = 3, FN_STEM7 = 4, FN_POOL = 5, FN_UPADD = 6, FN_SUMUP = 7, FN_DWCONV = 8, FN_AVGPOOL = 9,
-       FN_SCALEADD = 10, FN_SHUFFLE = 11, FN_HEAD = 12 };   // ops.FN_IDS
+       FN_SCALEADD = 10, FN_SHUFFLE = 11, FN_HEAD = 12, FN_TOPK = 13, FN_ASSIGN = 14 };   // ops.FN_IDS
 enum { REF_NULL = 0, REF_BUF = 1, REF_CONST = 2 };
 
 struct Op {
@@ -116,6 +119,10 @@ int run_op(const Op& o, hipStream_t s)
             return cp_scale_add_nhwc_f32(P[0], I[0], P[1], I[1], P[2], I[2], P[3], I[3], I[4], I[5], I[6], I[7], s);
         case FN_SHUFFLE:
             return cp_shuffle_concat_nhwc_f32(P[0], I[0], P[1], I[1], P[2], I[2], (long long)I[3], I[4], I[5], s);
+        case FN_TOPK:
+            return cp_decode_topk_f32(P[0], P[1], I[0], I[1], I[2], I[3], I[4], I[5], P[2], reinterpret_cast<int*>(P[3]), s);
+        case FN_ASSIGN:
+            return cp_decode_assign_f32(P[0], P[1], P[2], P[3], P[4], reinterpret_cast<const int*>(P[5]), I[0], I[1], I[2], I[3], I[4], P[6], s);
     }
     cp_set_error("plan: unknown launch function %u", o.fn);
     return 1;
@@ -136,6 +143,8 @@ bool arity_ok(const Op& o)
         case FN_AVGPOOL: return o.ptrs.size() == 2 && o.ints.size() == 5;
         case FN_SCALEADD: return o.ptrs.size() == 4 && o.ints.size() == 8;
         case FN_SHUFFLE: return o.ptrs.size() == 3 && o.ints.size() == 6;
+        case FN_TOPK: return o.ptrs.size() == 4 && o.ints.size() == 6;
+        case FN_ASSIGN: return o.ptrs.size() == 7 && o.ints.size() == 5;
     }
     return false;
 }
@@ -379,6 +388,13 @@ extern "C" int cp_plan_process(cp_plan* pl, const float* images, int K, float* d
     const int J = pl->outs[4].shape[1];
     CP_CHECK_ARG(pl->outs[2].shape[1] == 2 * J, "plan_process: hps has %d channels, hm_hp %d", pl->outs[2].shape[1], J);
     if (int rc = cp_plan_forward(pl, images, stream)) return rc;
+    // a plan compiled with the decode inside its schedule (Engine(decode_k = K): the peak extraction overlaps the last head
+    // convolutions, the whole step is one graph launch): its detections only need to be handed over
+    if (!pl->ops.empty() && pl->ops.back().fn == FN_ASSIGN && pl->ops.back().ints[4] == K) {
+        hipError_t e = hipMemcpyAsync(dets, pl->ops.back().ptrs[6], (size_t)B * K * (5 + 3 * J) * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream);
+        if (e != hipSuccess) { cp_set_error("plan_process: copy of the detections failed: %s", hipGetErrorString(e)); return 2; }
+        return 0;
+    }
     if (pl->ws_K < K) {
         if (pl->ws_scores) { (void)hipStreamSynchronize((hipStream_t)stream); (void)hipFree(pl->ws_scores); (void)hipFree(pl->ws_inds); }
         pl->ws_scores = nullptr; pl->ws_inds = nullptr; pl->ws_K = 0;

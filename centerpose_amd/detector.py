@@ -202,6 +202,14 @@ class MultiPoseDetector(BaseDetector):
 
     def process(self, images, return_time=False):
         """multi_pose.py:29-60.  images: float32 NCHW, mean/std-normalised, on the HIP device."""
+        loss = self.cfg.LOSS
+        if (not return_time and not self.cfg.TEST.FLIP_TEST and loss.REG_OFFSET and loss.HM_HP and loss.REG_HP_OFFSET
+                and not loss.MSE_LOSS and hasattr(self.model, "process")):
+            # no stage timing asked for and nothing to do between forward and decode: both in ONE graph replay (the peak
+            # extraction overlaps the last head convolutions).  `run()` keeps the two-stage form for its 'net' / 'dec' timers.
+            with torch.no_grad():
+                outputs, dets = self.model.process(images, self.cfg.TEST.TOPK)
+            return outputs, dets
         with torch.no_grad():
             torch.cuda.synchronize()
             outputs = self.model(images)            # hm (and hm_hp) already sigmoided (fused epilogue)

@@ -329,7 +329,7 @@ class Engine:
     """Static-shape inference engine for one (arch, batch, H, W)."""
 
     def __init__(self, arch, state_dict, batch, height=512, width=512, device="cuda", head_conv=None,
-                 sigmoid_heads=True, use_graph=True):
+                 sigmoid_heads=True, use_graph=True, decode_k=None):
         if not torch.cuda.is_available():
             raise _lib.CenterposeHipError("Engine needs a HIP device; there is no CPU fallback")
         _lib.lib()
@@ -354,6 +354,34 @@ class Engine:
         self.activation_bytes = pb.bytes_alloc
         self.graph = None
         self.use_graph = use_graph
+        self.dets, self.decode_k = None, None
+        if decode_k:
+            self._add_decode(int(decode_k), sigmoid_heads)
+
+    def _add_decode(self, K, sigmoid_heads):
+        """multi_pose_decode (lib/models/decode.py:235-308, called at multi_pose.py:55) as the last two launches of the
+        schedule: the whole of MultiPoseDetector.process without the flip test is then ONE graph replay, and the peak
+        extraction (needs hm / hm_hp only) runs on the second capture stream beside the remaining head convolutions."""
+        if sigmoid_heads is not True and set(sigmoid_heads) != {"hm", "hm_hp"}:
+            raise ValueError("decode inside the schedule needs the sigmoided hm and hm_hp heads")
+        hm, wh, hps, reg, hm_hp, hp_offset = self.outputs
+        B, J = hm.shape[0], hps.shape[1] // 2
+        with torch.cuda.device(self.device):
+            ws = torch.zeros((2, B, 1 + J, K), dtype=torch.float32, device=self.device)
+            self.dets = torch.zeros((B, K, 5 + 3 * J), dtype=torch.float32, device=self.device)
+        topk, assign = ops.decode_launches(hm, wh, hps, reg, hm_hp, hp_offset, K, ws, self.dets)
+        self.launches.append(("decode", "decode.nms_topk", 0, topk))
+        self.launches.append(("decode", "decode.pose_assign", 0, assign))
+        self.activation_bytes += 4 * (ws.numel() + self.dets.numel())
+        self.decode_k = K
+
+    def process(self, images):
+        """forward + decode in one replay (engines built with `decode_k`): -> (the six heads, dets [B, K, 5+3J]); static
+        buffers, overwritten by the next call."""
+        if self.dets is None:
+            raise _lib.CenterposeHipError("this engine was built without decode_k: call forward() and multi_pose_decode()")
+        outs = self.forward(images)
+        return outs, self.dets
 
     # -- on-disk plan (SURVEY 8 f4) --------------------------------------------------------------
     def save_plan(self, path):

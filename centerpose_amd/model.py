@@ -49,8 +49,8 @@ class BackBoneWithHead:
     def eval(self):
         return self
 
-    def engine_for(self, B, H, W):
-        key = (B, H, W)
+    def engine_for(self, B, H, W, decode_k=None):
+        key = (B, H, W) if decode_k is None else (B, H, W, int(decode_k))
         eng = self._engines.get(key)
         if eng is not None:
             self._engines.move_to_end(key)
@@ -58,7 +58,8 @@ class BackBoneWithHead:
         while len(self._engines) >= self.max_engines:
             self._engines.popitem(last=False)            # drop the least recently used plan before building the next one
         eng = engine.Engine(self.arch, self._sd, B, H, W, device=self.device, head_conv=self.head_conv,
-                            sigmoid_heads=("hm",) + (("hm_hp",) if self.sigmoid_hm_hp else ()), use_graph=self.use_graph)
+                            sigmoid_heads=("hm",) + (("hm_hp",) if self.sigmoid_hm_hp else ()), use_graph=self.use_graph,
+                            decode_k=decode_k)
         self._engines[key] = eng
         return eng
 
@@ -71,6 +72,12 @@ class BackBoneWithHead:
         return self.engine_for(B, H, W)(x)
 
     __call__ = forward
+
+    def process(self, x, K=100):
+        """forward + multi_pose_decode as ONE hipGraph replay (engine built with the decode inside its schedule):
+        -> ([hm, wh, hps, reg, hm_hp, hp_offset], dets [B, K, 56]); static buffers, overwritten by the next call."""
+        B, _, H, W = x.shape
+        return self.engine_for(B, H, W, decode_k=K).process(x)
 
 
 def create_model(arch, head_conv, cfg):

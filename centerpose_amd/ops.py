@@ -99,12 +99,17 @@ def marshal(fn, desc, ptrs, ints):
         return [ptrs[0], ints[0], ptrs[1], ints[1], ptrs[2], ints[2], ptrs[3]] + ints[3:]
     if fn == "cp_shuffle_concat_nhwc_f32":        # ptrs: x1, x2, out; ints: ld1, ld2, outLd, npix, h, hp
         return [ptrs[0], ints[0], ptrs[1], ints[1], ptrs[2], ints[2], ctypes.c_longlong(ints[3]), ints[4], ints[5]]
+    if fn == "cp_decode_topk_f32":                # ptrs: heat, hm_hp, ws_scores, ws_inds; ints: B, cat, J, H, W, K
+        return ptrs[:2] + ints + ptrs[2:]
+    if fn == "cp_decode_assign_f32":              # ptrs: wh, kps, reg, hp_offset, ws_scores, ws_inds, dets; ints: B, J, H, W, K
+        return ptrs[:6] + ints + [ptrs[6]]
     raise ValueError("unknown launch function %r" % fn)
 
 
 FN_IDS = {"cp_conv2d_f32": 1, "cp_conv3x3_winograd_f32": 2, "cp_dcn_v2_f32": 3, "cp_stem7x7_f32": 4,
           "cp_maxpool2d_nhwc_f32": 5, "cp_dw_deconv_add_nhwc_f32": 6, "cp_sum_up_nhwc_f32": 7, "cp_dwconv2d_nhwc_f32": 8,
-          "cp_global_avgpool_nhwc_f32": 9, "cp_scale_add_nhwc_f32": 10, "cp_shuffle_concat_nhwc_f32": 11, "cp_head3x3_1x1_f32": 12}
+          "cp_global_avgpool_nhwc_f32": 9, "cp_scale_add_nhwc_f32": 10, "cp_shuffle_concat_nhwc_f32": 11, "cp_head3x3_1x1_f32": 12,
+          "cp_decode_topk_f32": 13, "cp_decode_assign_f32": 14}
 
 
 def pad_rows(t, ldw):
@@ -436,3 +441,17 @@ def stem7x7_launch(x, wp, scale, shift, out, stride, relu=True):
 def stem7x7(x, wp, scale, shift, out, stride, relu=True):
     stem7x7_launch(x, wp, scale, shift, out, stride, relu).run()
     return out
+
+
+def decode_launches(hm, wh, hps, reg, hm_hp, hp_offset, K, ws, dets):
+    """multi_pose_decode (lib/models/decode.py:235-308) as two launch records for a schedule: peak extraction over hm / hm_hp
+    (`cp_decode_topk_f32`) and gathers + keypoint-to-person assignment (`cp_decode_assign_f32`).  `ws` is one float32 storage
+    [2, B, 1+J, K]: [0] = top-K scores, [1] = their flat indices (int32 bit patterns), `dets` [B, K, 5+3J]."""
+    B, cat, H, W = hm.shape
+    J = hps.shape[1] // 2
+    assert ws.dtype == torch.float32 and tuple(ws.shape) == (2, B, 1 + J, K) and tuple(dets.shape) == (B, K, 5 + 3 * J)
+    for t in (hm, wh, hps, reg, hm_hp, hp_offset, ws, dets):
+        assert t is None or t.is_contiguous()
+    topk = Launch("cp_decode_topk_f32", None, [hm, hm_hp, ws[0], ws[1]], [B, cat, J, H, W, K], out_index=2)
+    assign = Launch("cp_decode_assign_f32", None, [wh, hps, reg, hp_offset, ws[0], ws[1], dets], [B, J, H, W, K], out_index=6)
+    return topk, assign

@@ -241,6 +241,11 @@ def load_plan(path, device="cuda", use_graph=True):
         eng.activation_bytes = 4 * sum(p["buffers"])
         eng.graph = None
         eng.use_graph = use_graph
+        eng.dets, eng.decode_k = None, None
+        dec = [l for _, _, _, l in launches if l.fn == "cp_decode_assign_f32"]
+        if dec:                                                     # a plan compiled with the decode inside its schedule
+            Bd, Jd, _, _, Kd = dec[-1].ints
+            eng.dets, eng.decode_k = dec[-1].tensors[6].view(Bd, Kd, 5 + 3 * Jd), Kd
         streams = [o[5] for o in p["ops"]]
         eng.stream_plan = streams if any(streams) else None       # a file without a schedule: capture() makes one
     return eng

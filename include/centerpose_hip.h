@@ -171,6 +171,14 @@ int cp_decode_workspace_bytes(int B, int J, int K, size_t* scores_bytes, size_t*
 int cp_multi_pose_decode_f32(const float* heat, const float* wh, const float* kps, const float* reg,
                              const float* hm_hp, const float* hp_offset, int B, int cat, int J, int H,
                              int W, int K, float* dets, float* ws_scores, int* ws_inds, void* stream);
+/* The same decode as two launches (cp_multi_pose_decode_f32 = both, back to back), for schedules that want them as two graph
+ * nodes: cp_decode_topk_f32 = _nms + _topk + _topk_channel (decode.py:10-16,87-115) over hm / hm_hp -> ws_scores / ws_inds; it needs
+ * only those two heads, so a two-stream schedule runs it beside the remaining head convolutions.  cp_decode_assign_f32 = the gathers
+ * and the keypoint-to-person assignment (decode.py:240-308) -> dets. */
+int cp_decode_topk_f32(const float* heat, const float* hm_hp, int B, int cat, int J, int H, int W, int K, float* ws_scores,
+                       int* ws_inds, void* stream);
+int cp_decode_assign_f32(const float* wh, const float* kps, const float* reg, const float* hp_offset, const float* ws_scores,
+                         const int* ws_inds, int B, int J, int H, int W, int K, float* dets, void* stream);
 
 /* ---- plan handle: a whole network behind three calls -----------------------------
  * Replaces BackBoneWithHead.forward (lib/models/model.py:57-59: head_model(backbone_model(x))) for one compiled

@@ -299,6 +299,62 @@ def test_critical_path_schedule(arch, monkeypatch, tmp_path):
     assert all(torch.equal(p, q) for p, q in zip(ref, out2))
 
 
+@pytest.mark.parametrize("arch,hw", [("dla_34", 128), ("res_50", 160)])
+def test_decode_inside_the_schedule(arch, hw, tmp_path):
+    """Engine(decode_k=K): multi_pose_decode as the last two launches (cp_decode_topk_f32 / cp_decode_assign_f32) of the schedule.
+    One replay gives the six heads AND dets; dets are bit-equal to the stand-alone multi_pose_decode of the same heads (which
+    the golden decode tests pin against the reference), eagerly, from the two-stream graph, from a re-loaded plan, and from the
+    C plan handle (cp_plan_process hands the in-plan detections over instead of decoding again)."""
+    from centerpose_amd import cplan, engine, synth
+    from centerpose_amd.decode import multi_pose_decode
+    sd = synth.make_state_dict(arch)
+    x = synth.make_images(2, hw, hw, seed=9).cuda()
+    plain = engine.Engine(arch, sd, 2, hw, hw, use_graph=False)
+    heads = [t.clone() for t in plain(x)]
+    want = multi_pose_decode(heads[0], heads[1], heads[2], reg=heads[3], hm_hp=heads[4], hp_offset=heads[5], K=100)
+    with pytest.raises(Exception):
+        plain.process(x)                                      # built without decode_k: says so
+    for use_graph in (False, True):
+        eng = engine.Engine(arch, sd, 2, hw, hw, use_graph=use_graph, decode_k=100)
+        assert [l.fn for _, _, _, l in eng.launches[-2:]] == ["cp_decode_topk_f32", "cp_decode_assign_f32"] or use_graph
+        for _ in range(3):
+            outs, dets = eng.process(x)
+        torch.cuda.synchronize()
+        assert all(torch.equal(p, q) for p, q in zip(heads, outs)) and torch.equal(dets, want)
+    fns = [l.fn for _, _, _, l in eng.launches]
+    assert fns.index("cp_decode_topk_f32") < fns.index("cp_decode_assign_f32") == len(fns) - 1
+    path = str(tmp_path / "d.cpplan")
+    eng.save_plan(path)
+    e2 = engine.Engine.from_plan(path)
+    assert e2.decode_k == 100
+    for _ in range(2):
+        outs, dets = e2.process(x)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(heads, outs)) and torch.equal(dets, want)
+    cp = cplan.CPlan(path, use_graph=1)
+    for _ in range(3):
+        d = cp.process(x, K=100)
+    d50 = cp.process(x, K=50)                                   # another K: the plan's own decode does not apply, decoded separately
+    torch.cuda.synchronize()
+    assert torch.equal(d, want)
+    assert torch.equal(d50, multi_pose_decode(heads[0], heads[1], heads[2], reg=heads[3], hm_hp=heads[4], hp_offset=heads[5], K=50))
+    cp.close()
+
+
+def test_detector_process_one_replay_equals_two_stage():
+    """MultiPoseDetector.process without stage timing = forward + decode in one graph replay; with return_time (what run() asks
+    for) the two-stage form: same outputs, same dets."""
+    from centerpose_amd import config, detector, synth
+    cfg = config.get_cfg("res_50")
+    det = detector.MultiPoseDetector(cfg)
+    x = synth.make_images(1, 128, 128, seed=3).cuda()
+    o1, d1 = det.process(x)
+    o1, d1 = [t.clone() for t in o1], d1.clone()
+    o2, d2, t = det.process(x, return_time=True)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(o1, o2)) and torch.equal(d1, d2) and t > 0
+
+
 def test_dag_graph_is_bit_identical(monkeypatch):
     """CP_GRAPH=dag: the hipGraph assembled node by node from the data dependencies (csrc/graph_builder.cpp, transitively
     reduced edges) replays the same bits as the eager schedule."""
