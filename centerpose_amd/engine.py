@@ -521,13 +521,14 @@ class Engine:
         # streams / events must outlive the capture (destroying a capturing stream before hipStreamEndCapture crashes)
         self._capture_refs = (streams, events, fork)
 
-    def build_dag_graph(self):
+    def build_dag_graph(self, edges=None):
         """hipGraph with one node per launch and explicit edges from `dependencies()` (csrc/graph_builder.cpp): the whole
-        DAG instead of what two capture streams can express.  Returns a `_DagGraph` with `.replay()`."""
+        DAG instead of what two capture streams can express.  `edges`: use these predecessor lists instead (e.g. the chains +
+        cross edges of an N-stream schedule, tools/sched_try.py).  Returns a `_DagGraph` with `.replay()`."""
         import ctypes
         L = _lib.lib()
         L.cp_graph_stream.restype = ctypes.c_void_p
-        deps = self.dependencies()
+        deps = self.dependencies() if edges is None else edges
         # transitive reduction: an edge j -> i is dropped when i already follows j through another predecessor (every edge
         # that crosses executor streams is an event wait at replay time)
         n = len(deps)

@@ -96,7 +96,38 @@ NP = int(os.environ.get("NPROC", "2"))
 keep.append(capture_and_time(list(range(n)), None, "emission order, greedy placement (2 streams)"))
 o, a, mk = list_schedule(blevel)
 keep.append(capture_and_time(o, a, "list schedule (b-level), 2 streams, sim %.3f" % mk))
-if NP > 2:
+def time_dag(tag, g):
+    for _ in range(5): g.replay()
+    torch.cuda.synchronize()
+    same = all(torch.equal(x, y) for x, y in zip(eng.outputs, ref))
+    ts = []
+    for _ in range(40):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); g.replay(); e1.record(); e1.synchronize(); ts.append(e0.elapsed_time(e1))
+    ts.sort()
+    print("%-60s median %.3f ms p10 %.3f bit-identical %s" % (tag, ts[20], ts[4], same), flush=True)
+
+for npr in (2, 3, 4, 6):
+    o, a, mk = list_schedule(blevel, nproc=npr)
+    pos = {i: k for k, i in enumerate(o)}
+    eng.launches = [orig[i] for i in o]
+    deps = [sorted(pos[j] for j in deps0[i]) for i in o]
+    asg = [a[i] for i in o]
+    # explicit graph whose edges are what an npr-stream capture would record: the stream predecessor + the cross-stream dependencies
+    last = {}
+    edges = []
+    for k in range(n):
+        e = set(j for j in deps[k] if asg[j] != asg[k])
+        if asg[k] in last:
+            e.add(last[asg[k]])
+        last[asg[k]] = k
+        edges.append(sorted(e))
+    keep.append(eng.build_dag_graph(edges))
+    time_dag("explicit graph, chains of a %d-stream schedule, sim %.3f" % (npr, mk), keep[-1])
+keep.append(eng.build_dag_graph())
+time_dag("explicit graph, full DAG (transitively reduced), last order", keep[-1])
+if NP > 200:
+
     o, a, mk = list_schedule(blevel, nproc=NP)
     pos = {i: k for k, i in enumerate(o)}
     eng.launches = [orig[i] for i in o]
