@@ -675,7 +675,13 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
         const long long blocks_vs = (long long)a.B * cp_cdiv(a.H, 8) * cp_cdiv(a.W, WG_TW);
         // 64 input channels and >= 4 channel tiles (the head convs): V-stationary kernel, one block per spatial tile
         if (a.srcC[0] == 64 && ntiles >= 4 && blocks_vs >= 512) variant = 6401;
-        else variant = ntiles == 1 ? 11 : 12;
+        else {
+            variant = ntiles == 1 ? 11 : 12;
+            // a launch that cannot give every CU a block takes the 32-channel block: twice the blocks (the V transform is
+            // done twice as often, on CUs that would otherwise idle).  hrnet B=8 1 254 -> 1 405 img/s (its 128-/256-channel
+            // branches at 32x32 / 16x16 are 128 / 64 blocks of the 64-channel shape), dla_34 B=16 +0.9 %, B=1 +14 %.
+            if (variant == 12 && blocks_vs * ((ntiles + 1) / 2) < 300) variant = 11;
+        }
     }
     // 64xx: V-stationary kernel (C == 64), xx = number of channel-tile groups per spatial tile (0 -> 1)
     if (variant >= 6400 && variant < 6500) return a.srcC[0] == 64 ? launch_wino_vs64<0>(a, s, variant - 6400, WgHead{}) : -1;

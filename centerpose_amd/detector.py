@@ -194,6 +194,8 @@ class MultiPoseDetector(BaseDetector):
         self._perm = torch.tensor(perm, dtype=torch.int32, device="cuda")
 
     def _flip_merge(self, t, mode):
+        if t.shape[0] != 2:      # the reference's hm[0:1] + flip(hm[1:2]) (multi_pose.py:45-53) is only defined for image + mirrored twin
+            raise ValueError("FLIP_TEST needs a batch of exactly 2 (image + mirrored twin), got %d" % t.shape[0])
         out = torch.empty((1,) + tuple(t.shape[1:]), dtype=torch.float32, device=t.device)
         rc = _lib.lib().cp_flip_merge_f32(_lib.ptr(t.contiguous()), _lib.ptr(out), t.shape[1], t.shape[2], t.shape[3], mode,
                                           _lib.c_void_p(self._perm.data_ptr()), _lib.stream())

@@ -345,14 +345,18 @@ def test_detector_process_one_replay_equals_two_stage():
     """MultiPoseDetector.process without stage timing = forward + decode in one graph replay; with return_time (what run() asks
     for) the two-stage form: same outputs, same dets."""
     from centerpose_amd import config, detector, synth
-    cfg = config.get_cfg("res_50")
+    cfg = config.get_cfg("res_50", TEST__FLIP_TEST=False)
     det = detector.MultiPoseDetector(cfg)
     x = synth.make_images(1, 128, 128, seed=3).cuda()
     o1, d1 = det.process(x)
+    assert d1.data_ptr() == det.model.engine_for(1, 128, 128, decode_k=cfg.TEST.TOPK).dets.data_ptr()      # the one-replay path ran
     o1, d1 = [t.clone() for t in o1], d1.clone()
     o2, d2, t = det.process(x, return_time=True)
     torch.cuda.synchronize()
     assert all(torch.equal(p, q) for p, q in zip(o1, o2)) and torch.equal(d1, d2) and t > 0
+    flip = detector.MultiPoseDetector(config.get_cfg("res_50", TEST__FLIP_TEST=True))
+    with pytest.raises(ValueError):                 # the mirrored twin is missing: refuse instead of reading past the batch
+        flip.process(x)
 
 
 def test_dag_graph_is_bit_identical(monkeypatch):
