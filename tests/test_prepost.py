@@ -1,7 +1,8 @@
 """Pre-/post-processing around the hot path.
 
 CPU part: the oracle (oracle/prepost_np.py = OpenCV's 8-bit resize / warpAffine arithmetic + base_detector.py:32-62 +
-utils/post_process.py) against hand-computed cases -- cv2 itself is absent, so this is what pins it.
+utils/post_process.py) against hand-computed cases and against independent implementations of the same sampling (PyTorch's
+bilinear resize / grid_sample, Pillow) -- cv2 itself is absent, so this is what pins it.
 GPU part (-m gpu): the HIP kernels and the detector methods against that oracle, bit for bit, through the C ABI; and
 `run()` of the shipped hrnet configuration (FIX_RES false, TEST_SCALES [1,2], FLIP_TEST) stage by stage.
 """
@@ -18,6 +19,56 @@ MEAN, STD = [0.408, 0.447, 0.470], [0.289, 0.274, 0.278]      # lib/config/defau
 
 def _img(seed, h, w):
     return (np.random.RandomState(seed).rand(h, w, 3) * 255).astype(np.uint8)
+
+
+# ---------------------------------------------------------------- CPU: oracle vs independent implementations
+def _smooth(h, w):
+    yy, xx = np.mgrid[0:h, 0:w]
+    img = np.stack([127 + 100 * np.sin(xx / 7.0 + c) * np.cos(yy / 5.0 + 0.3 * c) for c in range(3)], -1)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("new", [(106, 74), (26, 18), (80, 50), (53, 37)])
+def test_oracle_resize_vs_torch_bilinear(new):
+    """cv2 cannot be imported here; PyTorch's own bilinear resize (half-pixel centres, float64) shares no code with the oracle's
+    restatement of OpenCV's 8-bit path (11-bit fixed-point coefficients, rounded result) and must agree to the rounding."""
+    import torch.nn.functional as F
+    img = _smooth(37, 53)
+    got = pp.resize_linear_u8(img, new[0], new[1]).astype(np.float64)
+    ref = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None].double(), size=(new[1], new[0]), mode="bilinear",
+                        align_corners=False)[0].permute(1, 2, 0).numpy()
+    d = np.abs(got - ref)
+    assert d.max() <= 1.0 and d.mean() <= 0.3            # round-to-nearest of the same sample: 0.5 + coefficient quantisation
+
+
+@pytest.mark.parametrize("M", [[[1.3, 0.0, -4.2], [0.0, 1.3, 2.7]], [[0.61, 0.0, 3.3], [0.0, 0.61, -1.9]], [[0.9, 0.2, 1.0], [-0.2, 0.9, 3.0]]])
+def test_oracle_warp_vs_grid_sample(M):
+    """The warpAffine restatement against F.grid_sample (bilinear, zero padding, align_corners: pixel centres at integer
+    coordinates, as OpenCV has them) at the inverse-mapped coordinates.  OpenCV quantises the source coordinates to 1/32 px,
+    so the two differ by at most gradient / 32 + rounding: a level or two inside the image, up to 255 / 32 at the zero border."""
+    import torch.nn.functional as F
+    img = _smooth(37, 53)
+    H, W = img.shape[:2]
+    M = np.asarray(M, np.float64)
+    ow, oh = 64, 48
+    got = pp.warp_affine_linear_u8(img, M, ow, oh).astype(np.float64)
+    Mi = pp.invert_affine(M)
+    ys, xs = np.mgrid[0:oh, 0:ow].astype(np.float64)
+    sx, sy = Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2], Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]
+    grid = torch.from_numpy(np.stack([2 * sx / (W - 1) - 1, 2 * sy / (H - 1) - 1], -1))[None]
+    ref = F.grid_sample(torch.from_numpy(img).permute(2, 0, 1)[None].double(), grid, mode="bilinear", padding_mode="zeros",
+                        align_corners=True)[0].permute(1, 2, 0).numpy()
+    d = np.abs(got - ref)
+    assert d.mean() <= 0.5 and (d > 1.5).mean() <= 0.02 and d.max() <= 1.0 + 255.0 / 32.0
+
+
+def test_oracle_resize_vs_pillow_upscale():
+    """Pillow's BILINEAR resize is a third implementation (it equals plain half-pixel bilinear when UP-scaling, the case the
+    shipped hrnet configuration's TEST_SCALES [1, 2] uses): within one grey level."""
+    Image = pytest.importorskip("PIL.Image")
+    img = _smooth(37, 53)
+    up = np.asarray(Image.fromarray(img).resize((106, 74), Image.BILINEAR)).astype(np.int32)
+    assert np.abs(up - pp.resize_linear_u8(img, 106, 74).astype(np.int32)).max() <= 1
 
 
 # ---------------------------------------------------------------- CPU: oracle vs hand-computed cases
