@@ -1,12 +1,10 @@
 #!/bin/bash
-OUT=gpurun_out/tmp; mkdir -p $OUT
-timeout 200 python bench.py --arch hrnet --batch 8 --no-cpu-baseline > $OUT/h8.json 2> $OUT/t.err
-python - <<'PY'
-import json
-l=json.load(open("gpurun_out/tmp/h8.json"))
-r=l["roofline"]
-print(l["value"], l["ms_per_step"], "sum", r["all_kernels_ms_per_step"])
-for k,v in list(r["kernels"].items())[:10]: print("   %-52s %3d %7.3f ms %5.1f%% alg %6.1f exe %6.1f TF %.2f TB/s" % (k[:52], v["launches"], v["ms_per_step"], 100*v["share"], v["algorithmic_tflops"], v["executed_tflops"], v["compulsory_tbps"]))
-PY
-timeout 200 python tools/layer_profile.py hrnet 8 > $OUT/layers_h8.txt 2>&1
-sort -k4 -n -r $OUT/layers_h8.txt | awk '{print $1, $2, $3, $5, $7, $9, $10, $12}' | head -30
+# round-2 profiles at HEAD
+OUT=gpurun_out/r2o; mkdir -p $OUT; export TMPDIR=/tmp
+timeout 400 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; echo "bench rc=$?"
+bash tools/gpu_profile.sh r2o pmc > $OUT/profile.log 2>&1
+CP_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/rocprof1 -o r2 -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile > $OUT/bench_under_rocprof_1stream.json 2> $OUT/rocprof1.err
+timeout 120 python tools/rocpd_summary.py $(find $OUT/rocprof1 -name "*.db" | head -1) > $OUT/kernel_stats_1stream.md 2>&1
+timeout 200 python tools/layer_profile.py res_50 16 > $OUT/layers_res50.txt 2>&1
+timeout 200 python tools/layer_profile.py hrnet 16 > $OUT/layers_hrnet.txt 2>&1
+head -c 700 $OUT/bench_line.json; echo; head -8 $OUT/kernel_stats_1stream.md
