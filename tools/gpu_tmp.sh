@@ -1,10 +1,2 @@
 #!/bin/bash
-# round-2 profiles at HEAD
-OUT=gpurun_out/r2o; mkdir -p $OUT; export TMPDIR=/tmp
-timeout 400 python bench.py > $OUT/bench_line.json 2> $OUT/bench.err; echo "bench rc=$?"
-bash tools/gpu_profile.sh r2o pmc > $OUT/profile.log 2>&1
-CP_STREAMS=1 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/rocprof1 -o r2 -- python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-profile > $OUT/bench_under_rocprof_1stream.json 2> $OUT/rocprof1.err
-timeout 120 python tools/rocpd_summary.py $(find $OUT/rocprof1 -name "*.db" | head -1) > $OUT/kernel_stats_1stream.md 2>&1
-timeout 200 python tools/layer_profile.py res_50 16 > $OUT/layers_res50.txt 2>&1
-timeout 200 python tools/layer_profile.py hrnet 16 > $OUT/layers_hrnet.txt 2>&1
-head -c 700 $OUT/bench_line.json; echo; head -8 $OUT/kernel_stats_1stream.md
+# scratch: the command of the moment for one gpurun call (see gpu_check.sh / gpu_profile.sh for the kept ones)
