@@ -325,6 +325,44 @@ class _DagGraph:
             pass
 
 
+def list_schedule(deps, durations, nstreams=2):
+    """List scheduling of a DAG on `nstreams` in-order streams.  deps[i] = indices (< i) launch i must follow, durations[i] its
+    time.  Priority = b-level (longest path from the launch to the end of the graph); the (ready launch, stream) pair that can
+    start earliest goes next, ties to the higher priority, then to the lower stream.  Returns (order, assign, makespan): `order`
+    is a permutation of range(n) that is a topological order (sorted by simulated start time), `assign[i]` the stream of launch
+    i, `makespan` the simulated length -- a lower bound of what the GPU does, because concurrent launches share it."""
+    n = len(deps)
+    assert len(durations) == n and all(all(0 <= j < i for j in d) for i, d in enumerate(deps))
+    children = [[] for _ in range(n)]
+    for i, d in enumerate(deps):
+        for j in d:
+            children[j].append(i)
+    blevel = [0.0] * n
+    for i in reversed(range(n)):
+        blevel[i] = durations[i] + max([blevel[c] for c in children[i]], default=0.0)
+    indeg = [len(set(d)) for d in deps]
+    ready = [i for i in range(n) if indeg[i] == 0]
+    free = [0.0] * nstreams
+    start, finish, assign = [0.0] * n, [0.0] * n, [0] * n
+    for _ in range(n):
+        best = None
+        for i in ready:
+            est = max([finish[j] for j in deps[i]], default=0.0)
+            for p in range(nstreams):
+                key = (max(est, free[p]), -blevel[i], p)
+                if best is None or key < best[0]:
+                    best = (key, i, p)
+        (t, _, _), i, p = best
+        ready.remove(i)
+        start[i], finish[i], free[p], assign[i] = t, t + durations[i], t + durations[i], p
+        for c in set(children[i]):
+            indeg[c] -= 1
+            if indeg[c] == 0:
+                ready.append(c)
+    order = sorted(range(n), key=lambda i: (start[i], i))     # a child never starts before its parents have finished
+    return order, assign, (max(finish) if n else 0.0)
+
+
 class Engine:
     """Static-shape inference engine for one (arch, batch, H, W)."""
 
@@ -434,40 +472,12 @@ class Engine:
         under-filled small-map launches: dla_34 B=16 8.19 -> 7.97 ms, hrnet B=8 6.96 -> 6.27 ms per forward, outputs
         bit-identical (tools/sched_try.py).  Any result is a topological order of the same DAG, so eager execution of
         the re-ordered list computes the same values.  Sets `self.launches` (new order) and `self.stream_plan`."""
-        n = len(self.launches)
         if durations is None:
             durations = [r["ms"] for r in self.profile_in_sequence(iters=3)]
-        deps = self.dependencies()
-        children = [[] for _ in range(n)]
-        for i, d in enumerate(deps):
-            for j in d:
-                children[j].append(i)
-        blevel = [0.0] * n
-        for i in reversed(range(n)):
-            blevel[i] = durations[i] + max([blevel[c] for c in children[i]], default=0.0)
-        indeg = [len(d) for d in deps]
-        ready = [i for i in range(n) if indeg[i] == 0]
-        free = [0.0] * nstreams
-        start, finish, assign = [0.0] * n, [0.0] * n, [0] * n
-        for _ in range(n):
-            best = None
-            for i in ready:
-                est = max([finish[j] for j in deps[i]], default=0.0)
-                for p in range(nstreams):
-                    key = (max(est, free[p]), -blevel[i], p)
-                    if best is None or key < best[0]:
-                        best = (key, i, p)
-            (t, _, _), i, p = best
-            ready.remove(i)
-            start[i], finish[i], free[p], assign[i] = t, t + durations[i], t + durations[i], p
-            for c in children[i]:
-                indeg[c] -= 1
-                if indeg[c] == 0:
-                    ready.append(c)
-        order = sorted(range(n), key=lambda i: (start[i], i))     # a child never starts before its parents have finished
+        order, assign, makespan = list_schedule(self.dependencies(), durations, nstreams)
         self.launches = [self.launches[i] for i in order]
         self.stream_plan = [assign[i] for i in order]
-        return max(finish)
+        return makespan
 
     def _run_branches(self, main, nstreams, deps, assign=None):
         """Enqueue the schedule on `nstreams` streams (main + side streams): independent branches of the graph

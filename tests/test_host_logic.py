@@ -193,3 +193,34 @@ def test_plan_format_serialize_parse_and_schema():
         plan.parse(memoryview(bytes(bad)))
     with pytest.raises((ValueError, struct.error)):             # truncated
         plan.parse(memoryview(blob[:200]))
+
+
+def test_list_schedule_properties():
+    """engine.list_schedule (the critical-path schedule of the launch DAG for the capture streams) on seeded random DAGs: the
+    order is a permutation that keeps every dependency, streams are in range, the simulated makespan lies between the critical
+    path and the serial sum, one stream = serial, a chain stays on one stream, independent equal tasks split evenly."""
+    import random
+    from centerpose_amd.engine import list_schedule
+    rnd = random.Random(7)
+    for trial in range(30):
+        n = rnd.randint(1, 60)
+        deps = [sorted(rnd.sample(range(i), min(i, rnd.randint(0, 3)))) for i in range(n)]
+        dur = [rnd.choice([0.0, 0.01, 0.05, 0.2, 1.0]) for _ in range(n)]
+        for ns in (1, 2, 3):
+            order, assign, mk = list_schedule(deps, dur, ns)
+            assert sorted(order) == list(range(n)) and all(0 <= a < ns for a in assign)
+            pos = {i: k for k, i in enumerate(order)}
+            assert all(pos[j] < pos[i] for i in range(n) for j in deps[i])
+            crit = [0.0] * n
+            for i in range(n):
+                crit[i] = dur[i] + max([crit[j] for j in deps[i]], default=0.0)
+            assert max(crit) - 1e-9 <= mk <= sum(dur) + 1e-9
+            if ns == 1:
+                assert abs(mk - sum(dur)) < 1e-9
+    order, assign, mk = list_schedule([[]] + [[i] for i in range(9)], [1.0] * 10, 2)        # a chain
+    assert order == list(range(10)) and len(set(assign)) == 1 and mk == 10.0
+    order, assign, mk = list_schedule([[] for _ in range(8)], [1.0] * 8, 2)                   # independent, equal
+    assert sorted(assign) == [0] * 4 + [1] * 4 and mk == 4.0
+    # the longer branch goes first: 0 -> {1 (short), 2 (long)} -> 3
+    order, assign, mk = list_schedule([[], [0], [0], [1, 2]], [1.0, 2.0, 3.0, 1.0], 2)
+    assert mk == 5.0 and assign[1] != assign[2]
