@@ -120,17 +120,28 @@ def roofline(eng, arch, B):
         f["bytes"] += r["bytes"]
         f["launches"] += 1
     all_ms = sum(f["ms"] for f in fam.values())
-    dom = max(fam, key=lambda k: fam[k]["ms"])
-    d = fam[dom]
+    # a kernel = one __global__ template; its tile instantiations (what rocprofv3 prints as separate rows) are summed: the DCNv2
+    # kernel runs as <64,64,...> and, where 128 output channels still fill the CUs, as <64,128,...>
+    grp = {}
+    for k, f in fam.items():
+        g = grp.setdefault(k.split("<")[0], {"ms": 0.0, "flops": 0.0, "exe_flops": 0.0, "bytes": 0, "launches": 0, "inst": []})
+        for key in ("ms", "flops", "exe_flops", "bytes", "launches"):
+            g[key] += f[key]
+        g["inst"].append(k)
+    dom = max(grp, key=lambda k: grp[k]["ms"])
+    d = grp[dom]
     mm = [fam[k] for k in fam if k.startswith(MFMA_KERNELS)]
     mm_ms = sum(f["ms"] for f in mm)
     tf = lambda flops, ms: flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     exe = tf(d["exe_flops"], d["ms"])
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(exe, 2), "peak": PEAK_F32_MFMA_TFLOPS,
             "unit": "TFLOP/s", "frac": round(exe / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-            "definition": "achieved = MFMA FLOPs executed by the dominant kernel (largest share of the step's GPU time) / its "
+            "definition": "achieved = MFMA FLOPs executed by the dominant kernel (the __global__ template with the largest share of the step's GPU time, all its tile instantiations) / its "
                           "time, HIP events between consecutive launches of the step; Winograd launches count 16/36 of their "
                           "algorithmic FLOPs",
+            "instantiations": {k: {"launches": fam[k]["launches"], "avg_launch_us": round(fam[k]["ms"] / fam[k]["launches"] * 1e3, 1),
+                                   "executed_tflops": round(tf(fam[k]["exe_flops"], fam[k]["ms"]), 1)}
+                               for k in sorted(d["inst"], key=lambda k: -fam[k]["ms"])},
             "algorithmic_tflops": round(tf(d["flops"], d["ms"]), 2),
             "time_share": round(d["ms"] / all_ms, 4), "launches": d["launches"],
             "avg_launch_us": round(d["ms"] / d["launches"] * 1e3, 1),
@@ -150,9 +161,9 @@ def roofline(eng, arch, B):
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
         if arch == "dla_34" and B == 16:
-            k = pmc["kernels"].get(dom)
-            if k:
-                roof["traffic"] = k["fetch_bytes_per_launch_corrected"] + k["write_bytes_per_launch"]
+            ks = [(pmc["kernels"][i], fam[i]["launches"]) for i in d["inst"] if i in pmc["kernels"]]
+            if ks:          # launch-weighted over the kernel's instantiations
+                roof["traffic"] = int(sum((k["fetch_bytes_per_launch_corrected"] + k["write_bytes_per_launch"]) * n for k, n in ks) / sum(n for _, n in ks))
                 roof["traffic_unit"] = "bytes per launch (avg)"
                 roof["traffic_source"] = "profiles/r2_pmc_traffic.json (rocprofv3 --pmc, collected offline with this command)"
     except (OSError, KeyError, ValueError):

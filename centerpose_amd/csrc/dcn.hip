@@ -414,7 +414,13 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
     }
     if (tile == 0) {
         if (d->ldw % 64 != 0) tile = (d->ldw % 32 == 0) ? 128032 : 0;
-        else tile = 64064;      // measured (MI355X, B = 16): 64x64 beats 128x64 by ~11 % on every DLA-34 shape (more, smaller blocks
+        else {
+            tile = 64064;
+            // 128 output channels per block (one gathered + blended A tile feeds twice the MFMAs) where that still leaves two
+            // blocks per CU: the 128-channel layers at 64x64 and the 256-channel one at 32x32 of DLA-34, B = 16 (+0.5 % end to end)
+            if (d->ldw % 128 == 0 && (long long)cp_cdiv(a.M, 64) * (d->ldw / 128) >= 500) tile = 64128;
+
+        }      // measured (MI355X, B = 16): 64x64 beats 128x64 by ~11 % on every DLA-34 shape (more, smaller blocks
                                 // interleave gather and MFMA phases better; the kernel is L1-gather-bound, not tile-reuse-bound)
     }
     int rc = 0;
@@ -423,15 +429,11 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
         case 128064: rc = launch_dcn<128, 64, 2, 2, 32>(a, s); break;
         case 64064: rc = launch_dcn<64, 64, 2, 2, 32>(a, s); break;
         case 64032: rc = launch_dcn<64, 32, 4, 1, 16>(a, s); break;
-        case 128128: rc = launch_dcn<128, 128, 2, 2, 32>(a, s); break;
         case 64128: rc = launch_dcn<64, 128, 2, 2, 32>(a, s); break;
         case 2064064: rc = launch_dcn<64, 64, 2, 2, 32, 2>(a, s); break;      // 32-channel (full cache line) gathers
-        case 2128064: rc = launch_dcn<128, 64, 2, 2, 32, 2>(a, s); break;
         case 6064128: rc = (d->ldw % 128 == 0) ? launch_dcn<64, 128, 2, 2, 32>(a, s) : launch_dcn<64, 64, 2, 2, 32>(a, s); break;
-        case 6128128: rc = (d->ldw % 128 == 0) ? launch_dcn<128, 128, 2, 2, 32>(a, s) : launch_dcn<64, 64, 2, 2, 32>(a, s); break;
         case 5064064: rc = launch_dcn<64, 64, 2, 2, 32, 1, 2>(a, s); break;     // two-deep gather prefetch
         case 5064128: rc = (d->ldw % 128 == 0) ? launch_dcn<64, 128, 2, 2, 32, 1, 2>(a, s) : launch_dcn<64, 64, 2, 2, 32, 1, 2>(a, s); break;
-        case 5128064: rc = launch_dcn<128, 64, 2, 2, 32, 1, 2>(a, s); break;
         case 7064064: rc = (d->C % 32 == 0) ? launch_dcn<64, 64, 2, 2, 32, 1, 3>(a, s) : launch_dcn<64, 64, 2, 2, 32>(a, s); break;   // full-line gathers
         default: CP_CHECK_ARG(false, "dcn_v2: unsupported tile %d (ldw=%d)", tile, d->ldw);
     }

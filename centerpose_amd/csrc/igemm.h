@@ -128,7 +128,8 @@ __device__ __forceinline__ void ig_load_b(const ConvArgs& a, int k0, int n0, int
 #pragma unroll
     for (int s = 0; s < T::B_SLOTS; ++s) {
         const int idx = tid + s * IG_THREADS;
-        if (T::B_F4 % IG_THREADS == 0 || idx < T::B_F4) br[s] = *reinterpret_cast<const float4*>(w + (size_t)(n0 + (idx >> 2)) * a.K + k0 + (idx & 3) * 4);
+        if constexpr (T::B_F4 % IG_THREADS == 0) br[s] = ig_ldg4(w + (size_t)(n0 + (idx >> 2)) * a.K + k0 + (idx & 3) * 4);
+        else if (idx < T::B_F4) br[s] = ig_ldg4(w + (size_t)(n0 + (idx >> 2)) * a.K + k0 + (idx & 3) * 4);
     }
 }
 template <class T>
