@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the per-kernel roofline pass (for rocprofv3 runs)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--gather-check", action="store_true",
+                    help="N > 1: after the timed region compare every rank's gathered dets (checksum exchange) and its own shard's slot")
     return ap.parse_args()
 
 
@@ -73,16 +75,18 @@ def cpu_model_name():
 
 def cpu_baseline(arch):
     """Oracle ("port") on the host cores, 512x512, bounded sample: the metric's workload (forward + sigmoid + decode of
-    `arch`), and BASELINE.json configs[0] (res_50, single image; plus batch 8) split into forward and decode."""
+    `arch`), and BASELINE.json configs[0] (res_50, single image; plus batch 8) split into forward and decode.  Each workload
+    is timed at several torch thread counts inside the same time budget and the BEST is reported with its thread count (one
+    512x512 image on 64 threads is oversubscribed: VERDICT r2 #8)."""
     import numpy as np
     import torch
     from centerpose_amd import synth
     from oracle import decode_np, nets_torch
-    ncores = max(1, (os.cpu_count() or 2) // 2)          # physical cores (2 threads per core here)
-    ncores = min(ncores, 64)                              # one socket: oneDNN scales poorly across sockets
-    torch.set_num_threads(ncores)
+    phys = max(1, (os.cpu_count() or 2) // 2)            # physical cores (2 threads per core here)
+    sweep = sorted({t for t in (8, 16, 32, 64) if t <= max(8, phys)})
 
-    def timed(a, x, min_s, max_imgs):
+    def timed(a, x, min_s, max_imgs, nthreads):
+        torch.set_num_threads(nthreads)
         sd = synth.make_state_dict(a)
         nets_torch.process(a, sd, x[:1])                  # warm-up (thread pool, oneDNN primitives)
         n = fwd = dec = 0
@@ -96,15 +100,21 @@ def cpu_baseline(arch):
             tc = time.perf_counter()
             fwd, dec, n = fwd + tb - ta, dec + tc - tb, n + x.shape[0]
             if tc - t0 >= min_s or n >= max_imgs:
-                return {"images": n, "seconds": round(tc - t0, 2), "images_per_sec": round(n / (tc - t0), 3),
+                return {"images": n, "seconds": round(tc - t0, 2), "images_per_sec": round(n / (tc - t0), 3), "threads": nthreads,
                         "forward_ms_per_image": round(fwd / n * 1e3, 2), "decode_ms_per_image": round(dec / n * 1e3, 2)}
-    main = timed(arch, synth.make_images(2), 8.0, 16)
-    r1 = timed("res_50", synth.make_images(1), 4.0, 32)
-    r8 = timed("res_50", synth.make_images(8), 3.0, 32)
-    return {"value": main["images_per_sec"], "unit": "images/sec", "cores": ncores, "kind": "port",
-            "sample": "%d images of 512x512 (%s forward + sigmoid + decode, batch 2, torch %s CPU fp32 oracle) in %.1f s"
-                      % (main["images"], arch, torch.__version__, main["seconds"]),
-            "cpu_model": cpu_model_name(), arch: main, "res_50_b1": r1, "res_50_b8": r8}
+
+    def best(a, x, min_s, max_imgs):
+        runs = [timed(a, x, min_s / len(sweep), max_imgs, t) for t in sweep]
+        top = max(runs, key=lambda r: r["images_per_sec"])
+        top["sweep_images_per_sec"] = {str(r["threads"]): r["images_per_sec"] for r in runs}
+        return top
+    main = best(arch, synth.make_images(2), 10.0, 8)
+    r1 = best("res_50", synth.make_images(1), 6.0, 16)
+    r8 = best("res_50", synth.make_images(8), 6.0, 8)
+    return {"value": main["images_per_sec"], "unit": "images/sec", "cores": main["threads"], "kind": "port",
+            "sample": "%d images of 512x512 (%s forward + sigmoid + decode, batch 2, torch %s CPU fp32 oracle) in %.1f s at the best of "
+                      "%s torch threads" % (main["images"], arch, torch.__version__, main["seconds"], sweep),
+            "cpu_model": cpu_model_name(), "physical_cores": phys, arch: main, "res_50_b1": r1, "res_50_b8": r8}
 
 
 def roofline(eng, arch, B):
@@ -159,16 +169,26 @@ def roofline(eng, arch, B):
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction +
     # WRITE_SIZE; separate --pmc runs of this same command, see profiles/README.md) -- NOT collected in this run
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))
+        import glob
+        src = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]      # the latest round's passes
+        pmc = json.load(open(src))
         if arch == "dla_34" and B == 16:
             ks = [(pmc["kernels"][i], fam[i]["launches"]) for i in d["inst"] if i in pmc["kernels"]]
             if ks:          # launch-weighted over the kernel's instantiations
                 roof["traffic"] = int(sum((k["fetch_bytes_per_launch_corrected"] + k["write_bytes_per_launch"]) * n for k, n in ks) / sum(n for _, n in ks))
                 roof["traffic_unit"] = "bytes per launch (avg)"
-                roof["traffic_source"] = "profiles/r2_pmc_traffic.json (rocprofv3 --pmc, collected offline with this command)"
-    except (OSError, KeyError, ValueError):
+                roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, collected offline with this command)" % os.path.basename(src)
+    except (OSError, KeyError, ValueError, IndexError):
         pass
     return roof
+
+
+def make_engine(arch="dla_34", B=16, dev="cuda", use_graph=True):
+    """THE timed configuration: seeded synthetic checkpoint, B x 3 x 512 x 512, the decode inside the engine's schedule
+    (forward + sigmoid + decode = ONE two-stream hipGraph replay per step).  tests/test_engine_hip.py::
+    test_timed_configuration_parity builds its engine through this function, so what is parity-tested is what is timed."""
+    from centerpose_amd import engine, synth
+    return engine.Engine(arch, synth.make_state_dict(arch), B, 512, 512, device=dev, use_graph=use_graph, decode_k=100)
 
 
 def main():
@@ -190,14 +210,13 @@ def main():
     dev = torch.device("cuda", local)
 
     B = args.batch
-    sd = synth.make_state_dict(args.arch)
     # the decode is part of the engine's schedule (decode_k): forward + sigmoid + decode = ONE hipGraph replay per step, the
     # peak extraction overlapping the last head convolutions on the second capture stream
-    eng = engine.Engine(args.arch, sd, B, 512, 512, device=dev, use_graph=not args.no_graph, decode_k=100)
+    eng = make_engine(args.arch, B, dev, use_graph=not args.no_graph)
     lo, _ = cpd.shard_range(B * world, rank, world)
     images = synth.make_images(B, seed=317 + lo).to(dev)      # this rank's shard, resident in HBM
     eng.input.copy_(images)
-    gat = cpd.DetsGatherer(global_batch=B * world)
+    gat = cpd.DetsGatherer(global_batch=B * world, time_waits=True)
 
     def step():
         """one batch through backbone + heads + decode; the all-gather of its detections is left running on the side
@@ -226,10 +245,29 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    rank_ms = {"min": elapsed / args.steps * 1e3, "max": elapsed / args.steps * 1e3}
+    wait_total, wait_max = gat.exposed_wait_ms()
+    gather_info = None
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        cdev = dev if dist.get_backend() == "nccl" else "cpu"
+        own = torch.tensor([elapsed, wait_total, wait_max], dtype=torch.float64, device=cdev)
+        hi, lo = own.clone(), own.clone()
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        elapsed = float(hi[0].item())                 # the contract: MAX over ranks
+        rank_ms = {"min": float(lo[0].item()) / args.steps * 1e3, "max": elapsed / args.steps * 1e3}
+        gather_info = {"collective": "all_gather_into_tensor of dets[%d,100,56] f32 per rank (%d B), side stream, collected one step later"
+                                     % (B, B * 100 * 56 * 4),
+                       "exposed_wait_ms_per_step": {"max_over_ranks": round(float(hi[1].item()) / args.steps, 4),
+                                                    "min_over_ranks": round(float(lo[1].item()) / args.steps, 4)},
+                       "longest_single_wait_ms": round(float(hi[2].item()), 4),
+                       "timed_with": "HIP events around the compute stream's wait for the side-stream gather" if gat.time_waits
+                                     else "not timed (host-staged gloo gather is synchronous)"}
+        if args.gather_check:
+            _, last = eng.process(eng.input)
+            ok, _, msg = cpd.check_gathered(cpd.gather_dets(last.clone(), B * world), last, B * world)
+            gather_info["check"] = msg
+            assert ok, msg
     assert out.shape == (B * world, 100, 56)
 
     if rank == 0:
@@ -247,6 +285,9 @@ def main():
                            "weights": "seeded synthetic checkpoint (reference key layout)"},
                 "ranks": dist.get_world_size() if world > 1 else 1,
                 "backend": dist.get_backend() if world > 1 else None,
+                "rank_ms_per_step": {k: round(v, 3) for k, v in rank_ms.items()},
+                "gather": gather_info,
+                "graph_capture": eng.capture_mode if not args.no_graph else "eager",
                 "step_ms": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3),
                             "min": round(per[0], 3), "max": round(per[-1], 3), "source": "HIP events per step on the launch stream"},
                 "end_to_end_tflops": round(eng.flops_per_image * value / world / 1e12, 2),

@@ -32,6 +32,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline int cp_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: one guard per (kernel instantiation,
+// device), safe across threads.  `need(bytes)` is true the first time this device asks for at least `bytes`.
+#include <atomic>
+struct CpLdsGuard {
+    std::atomic<int> have[16] = {};
+    bool need(int bytes) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        std::atomic<int>& h = have[d & 15];
+        int cur = h.load(std::memory_order_relaxed);
+        while (cur < bytes)
+            if (h.compare_exchange_weak(cur, bytes)) return true;
+        return false;
+    }
+};
+
 // activation codes of the C ABI (include/centerpose_hip.h).  h-swish / h-sigmoid as the reference writes them
 // (lib/models/backbones/mobilenet/mobilenetv3.py:87-96): x * relu6(x + 3) / 6 and relu6(x + 3) / 6, true division.
 #define CP_ACT_NONE_ 0

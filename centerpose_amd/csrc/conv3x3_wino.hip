@@ -148,12 +148,17 @@ __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, co
 }
 
 // ---- fused head: [3x3 conv + bias + ReLU] -> 1x1 conv (+ bias, + sigmoid) without the intermediate ever leaving the CU ----
-// lib/models/heads/keypoint.py:14-37: every branch is conv3x3(C -> head_conv) -> ReLU -> conv1x1(head_conv -> n).  For the
-// branches with n <= 2 outputs (hm, wh, reg, hp_offset) the 1x1 is applied HERE, on the channel tile that has just been reduced:
-// each thread multiplies its 4 channels of 4 output pixels with the matching 1x1 weights and keeps 4 * N2 partial sums in
-// registers across the block's channel tiles; at the end the 8 lanes that share a pixel are summed with three xor-shuffles
-// (fixed order: deterministic) and lane 0 writes the reference's NCHW output.  The 268 MB mid tensor of a B = 16 head (written
-// by this kernel, read back by the 1x1 launch: 2 x 268 MB per head) no longer exists for those four branches.
+// lib/models/heads/keypoint.py:14-37: every branch is conv3x3(C -> head_conv) -> ReLU -> conv1x1(head_conv -> n).  The 268 MB mid
+// tensor of a B = 16 head (written by the 3x3 launch, read back by the 1x1 launch: 2 x 268 MB per head) never exists:
+// * n <= 2 outputs (hm, wh, reg, hp_offset): the 1x1 is applied on the channel tile that has just been reduced: each thread
+//   multiplies its 4 channels of 4 output pixels with the matching 1x1 weights and keeps 4 * N2 partial sums in registers across
+//   the block's channel tiles; at the end the 8 lanes that share a pixel are summed with three xor-shuffles (fixed order:
+//   deterministic) and lane 0 writes the reference's NCHW output.
+// * more outputs (hps 34, hm_hp 17; round 3, MM = 1): the ReLU'd 128-pixel x 32-channel tile goes to LDS (`mid`, 18 KB) and the 1x1
+//   over it runs as a second MFMA phase, D[out j][pixel] += w2[j][c] * mid[pixel][c]: per channel tile and wave 16
+//   v_mfma_f32_32x32x2f32 (+12.5 % on the 128 of the 3x3) into ONE 32x32 accumulator that lives across the block's channel
+//   tiles.  Outputs 0..31 come from the MFMA phase; outputs 32, 33 (hps) ride on the n <= 2 register path above.  One
+//   reduction buffer + `mid` (55 KB, two blocks per CU) instead of two reduction buffers, two barriers per channel tile.
 struct WgHead {
     const float* w2;     // [N2][ld2] 1x1 weights, row-major over the mid channels
     const float* b2;     // [N2]
@@ -161,10 +166,15 @@ struct WgHead {
     int n2, ld2, act2;
 };
 
-template <int N2>
+#define WGH_LDM 36                                  // `mid` row pitch in floats: 16-lane b128 groups on distinct 4-bank groups
+#define WGH_MID (128 * WGH_LDM)                      // [pixel 128][32 channels] floats
+
+template <int N2, int MM>
 __device__ __forceinline__ void wg_output_tile_head(const ConvArgs& a, const WgHead& hd, float* red, const f32x16 (&acc)[4], int xi, int h,
-                                                    int m, int tid, int yb, int x0, int tile, float (&acc2)[2][2][N2])
+                                                    int m, int tid, int yb, int x0, int tile, float (&acc2)[2][2][N2 > 0 ? N2 : 1],
+                                                    f32x16& acc2m, float* mid)
 {
+    constexpr int J0 = MM ? 32 : 0;                  // first output channel of the register (VALU) path
     float* wp = red + (xi * 64 + m) * WG_LDR + 4 * h;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -174,18 +184,33 @@ __device__ __forceinline__ void wg_output_tile_head(const ConvArgs& a, const WgH
         *reinterpret_cast<wg_v4*>(wp + 8 * j) = (q[0] + q[1]) + q[2];
         *reinterpret_cast<wg_v4*>(wp + 32 * WG_LDR + 8 * j) = (q[1] - q[2]) - q[3];
     }
-    int itn[2], itrd[2];
-    wg_v4 sc[2], sh[2], w2r[2][N2];
+    int itn[2], itrd[2], itmid[2];
+    wg_v4 sc[2], sh[2], w2r[2][N2 > 0 ? N2 : 1];
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int item = tid + it * IG_THREADS;
         const int n4 = item & 7, bb = (item >> 3) & 1, mi = item >> 4;
         itn[it] = tile * 32 + n4 * 4;
         itrd[it] = (bb * 32 + mi) * WG_LDR + n4 * 4;
+        itmid[it] = (32 * (mi >> 3) + 2 * (mi & 7) + bb) * WGH_LDM + n4 * 4;      // pixel (row 2*(mi>>3), column 2*(mi&7)+bb) of the 8x16 tile, row-major
         sc[it] = *reinterpret_cast<const wg_v4*>(a.scale + itn[it]);
         sh[it] = *reinterpret_cast<const wg_v4*>(a.shift + itn[it]);
 #pragma unroll
-        for (int j = 0; j < N2; ++j) w2r[it][j] = *reinterpret_cast<const wg_v4*>(hd.w2 + (size_t)j * hd.ld2 + itn[it]);
+        for (int j = 0; j < N2; ++j) w2r[it][j] = *reinterpret_cast<const wg_v4*>(hd.w2 + (size_t)(J0 + j) * hd.ld2 + itn[it]);
+    }
+    // MM: this wave's 1x1 weight fragments for the MFMA phase, straight from the row-major w2: lane (j = lane % 32, g = lane / 32)
+    // takes channels tile*32 + 8s + 4g .. +3 of output row j (rows >= n2 read row n2 - 1 and are zeroed) -- the four loads of a lane
+    // cover one 128-byte line; issued here so that they land under the barrier and the reduction
+    wg_v4 w2f[MM ? 4 : 1];
+    if constexpr (MM) {
+        const int nmm = hd.n2 < 32 ? hd.n2 : 32;
+        const bool live = m < nmm;
+        const float* wrow = hd.w2 + (size_t)(live ? m : nmm - 1) * hd.ld2 + tile * 32 + 4 * h;
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const float4 t4 = ig_ldg4(wrow + 8 * s4);
+            w2f[s4] = live ? (wg_v4){t4.x, t4.y, t4.z, t4.w} : (wg_v4){0.f, 0.f, 0.f, 0.f};
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -204,6 +229,22 @@ __device__ __forceinline__ void wg_output_tile_head(const ConvArgs& a, const WgH
                 const wg_v4 w = w2r[it][j];
                 acc2[it][aa][j] = fmaf(v.w, w.w, fmaf(v.z, w.z, fmaf(v.y, w.y, fmaf(v.x, w.x, acc2[it][aa][j]))));
             }
+            if constexpr (MM) *reinterpret_cast<wg_v4*>(mid + itmid[it] + aa * 16 * WGH_LDM) = v;      // row oy + aa: 16 pixels further
+        }
+    }
+    if constexpr (MM) {
+        // second MFMA phase: wave xi owns pixels 32*xi .. +31 of the tile (two rows of 16); D[out j][pixel]
+        __syncthreads();
+        const float* mp = mid + (32 * xi + m) * WGH_LDM + 4 * h;
+        wg_v4 mf[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) mf[s4] = wg_lds4(mp + 8 * s4);
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            acc2m = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[s4].x, mf[s4].x, acc2m, 0, 0, 0);
+            acc2m = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[s4].y, mf[s4].y, acc2m, 0, 0, 0);
+            acc2m = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[s4].z, mf[s4].z, acc2m, 0, 0, 0);
+            acc2m = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[s4].w, mf[s4].w, acc2m, 0, 0, 0);
         }
     }
 }
@@ -425,8 +466,11 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
 #define WGV_SLOTS ((WGV_F4 + IG_THREADS - 1) / IG_THREADS)  // 12
 #define WGV_CG (10 * WG_PWP * 4)                            // floats per 4-channel plane
 #define WGV_SMEM_FLOATS (2 * WG_RED)                        // two reduction buffers (73.7 KB) >= the 51.2 KB patch
+#define WGV_SMEM_FLOATS_MM (WG_RED + WGH_MID)               // MM: one reduction buffer + the mid tile (55.3 KB) >= the patch
 
-template <int N2>       // 0: plain conv; 1 / 2: fused head with N2 output channels of the 1x1 (wg_output_tile_head)
+// N2: output channels of the head's 1x1 on the register path (0: none); MM = 1: second MFMA phase for outputs 0..31 of the 1x1
+// (then the register path handles outputs 32 .. 32 + N2 - 1).  <0, 0> = plain convolution.
+template <int N2, int MM>
 __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const ConvArgs a, const WgGrid gd, int NL, const WgHead hd)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -530,6 +574,9 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int j = 0; j < (N2 > 0 ? N2 : 1); ++j) acc2[i][k][j] = 0.f;
+    f32x16 acc2m;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2m[r] = 0.f;
 #pragma unroll 1
     for (int nt = nt0; nt < nt1; ++nt) {
         f32x16 acc[4];
@@ -559,11 +606,29 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // two reduction buffers: tile i+2 overwrites buffer i&1 only after the barrier inside tile i+1's output stage
-        if constexpr (N2 > 0) wg_output_tile_head<N2>(a, hd, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, y0, x0, nt, acc2);
+        // two reduction buffers: tile i+2 overwrites buffer i&1 only after the barrier inside tile i+1's output stage.
+        // MM: ONE reduction buffer + `mid`; the second barrier of the output stage (between the mid writes and the MFMA phase) is
+        // what separates this tile's reads of the reduction buffer from the next tile's writes, and the first barrier of the
+        // next tile separates this tile's mid reads from the next tile's mid writes.
+        if constexpr (MM) wg_output_tile_head<N2, 1>(a, hd, smem, acc, xi, h, m, tid, y0, x0, nt, acc2, acc2m, smem + WG_RED);
+        else if constexpr (N2 > 0) wg_output_tile_head<N2, 0>(a, hd, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, y0, x0, nt, acc2, acc2m, nullptr);
         else wg_output_tile(a, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, b, y0, x0, nt, true);
     }
+    if constexpr (MM) {
+        // D[out j][pixel]: lane (pixel 32*xi + m of the 8x16 tile, row group h) holds outputs j = (r & 3) + 8 * (r >> 2) + 4 * h
+        const size_t HW = (size_t)a.H * a.W;
+        const int p = 32 * xi + m, ox = x0 + (p & 15), oy = y0 + (p >> 4);
+        const int nmm = hd.n2 < 32 ? hd.n2 : 32;
+        if (ox < a.W && oy < a.H) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int j = (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (j < nmm) hd.out2[((size_t)b * hd.n2 + j) * HW + (size_t)oy * a.W + ox] = cp_act(acc2m[r] + hd.b2[j], hd.act2);
+            }
+        }
+    }
     if constexpr (N2 > 0) {
+        constexpr int J0 = MM ? 32 : 0;
         // the 8 lanes tid & 7 = 0..7 hold the partial sums of one (tile, column) over 32 channels each: sum them in a fixed
         // order, add the bias, apply the output activation and store the reference's NCHW planes
         const size_t HW = (size_t)a.H * a.W;
@@ -580,8 +645,8 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
                     v += __shfl_xor(v, 1);
                     v += __shfl_xor(v, 2);
                     v += __shfl_xor(v, 4);
-                    if ((tid & 7) == 0 && j < hd.n2 && ox < a.W && oy + aa < a.H)
-                        hd.out2[((size_t)b * hd.n2 + j) * HW + (size_t)(oy + aa) * a.W + ox] = cp_act(v + hd.b2[j], hd.act2);
+                    if ((tid & 7) == 0 && J0 + j < hd.n2 && ox < a.W && oy + aa < a.H)
+                        hd.out2[((size_t)b * hd.n2 + J0 + j) * HW + (size_t)(oy + aa) * a.W + ox] = cp_act(v + hd.b2[J0 + j], hd.act2);
                 }
         }
     }
@@ -595,13 +660,12 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
     auto kern = conv3x3_wino_kernel<MT, NT, KS, NB>;
     using Geo = WgGeo<MT, KS>;
     const int smem = Geo::SMEM_FLOATS * 4;
-    static bool attr = false;          // once per instantiation, on the first (warm-up) launch: not legal inside a stream capture
-    if (!attr && smem > 64 * 1024) {
+    static CpLdsGuard guard;           // once per (instantiation, device), on the first (warm-up) launch: not legal inside a stream capture
+    if (smem > 64 * 1024 && guard.need(smem)) {
         if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
             cp_set_error("conv3x3_winograd: cannot reserve %d B LDS", smem);
             return 2;
         }
-        attr = true;
     }
     WgGrid gd;
     gd.tilesX = cp_cdiv(a.W, WG_TW); gd.tilesY = cp_cdiv(a.H, Geo::TH);
@@ -616,15 +680,15 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
     return 0;
 }
 
-template <int N2>
+template <int N2, int MM = 0>
 static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups, const WgHead& hd)
 {
-    const int smem = WGV_SMEM_FLOATS * 4;
-    static bool attr = false;
-    if (!attr) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_vs64_kernel<N2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    const int smem = (MM ? WGV_SMEM_FLOATS_MM : WGV_SMEM_FLOATS) * 4;
+    static_assert(WGV_SMEM_FLOATS_MM >= WGV_CGS * WGV_CG, "the 64-channel patch must fit the MM layout");
+    static CpLdsGuard guard;
+    if (guard.need(smem)) {
+        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_vs64_kernel<N2, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) { cp_set_error("conv3x3_winograd: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
-        attr = true;
     }
     WgGrid gd;
     gd.tilesX = cp_cdiv(a.W, WG_TW); gd.tilesY = cp_cdiv(a.H, 8);
@@ -637,24 +701,28 @@ static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups, const
     const long long grid = (long long)a.B * gd.tilesX * gd.tilesY * gd.ntb;
     const long long dmax = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
     if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd: grid %lld too large", grid); return 1; }
-    hipLaunchKernelGGL(conv3x3_wino_vs64_kernel<N2>, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd, NL, hd);
-    cp_note_kernel(N2 ? "conv3x3_wino_vs64_kernel<%d>" : "conv3x3_wino_vs64_kernel<0>", N2);
+    hipLaunchKernelGGL((conv3x3_wino_vs64_kernel<N2, MM>), dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd, NL, hd);
+    cp_note_kernel("conv3x3_wino_vs64_kernel<%d, %d>", N2, MM);
     return 0;
 }
 
-// [3x3 conv + bias + ReLU] + 1x1 conv of a KeypointHead branch with n2 <= 2 outputs in one launch.  Returns -1 when the shape is
+// [3x3 conv + bias + ReLU] + 1x1 conv of a KeypointHead branch with n2 <= 34 outputs in one launch.  Returns -1 when the shape is
 // not the fused kernel's (64 input channels, mid channels a multiple of 32, NHWC, 16-byte aligned operands).
 int cp_launch_head3x3_1x1(const ConvArgs& a, const float* w2, const float* b2, float* out2, int n2, int ld2, int act2, hipStream_t s)
 {
     const bool ok = a.nsrc == 1 && a.kh == 3 && a.kw == 3 && a.sy == 1 && a.sx == 1 && a.py == 1 && a.px == 1 && a.Ho == a.H &&
                     a.Wo == a.W && a.srcC[0] == 64 && a.srcLd[0] % 4 == 0 && a.Cout % 32 == 0 && a.act == CP_ACT_RELU && !a.res &&
-                    n2 >= 1 && n2 <= 2 && ld2 % 4 == 0 && ld2 >= a.Cout &&
+                    n2 >= 1 && n2 <= 34 && ld2 % 4 == 0 && ld2 >= a.Cout &&
                     (((size_t)a.src[0] | (size_t)a.w | (size_t)w2 | (size_t)a.scale | (size_t)a.shift) & 15) == 0 &&
                     (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
     if (!ok) return -1;
     WgHead hd;
     hd.w2 = w2; hd.b2 = b2; hd.out2 = out2; hd.n2 = n2; hd.ld2 = ld2; hd.act2 = act2;
-    return n2 == 1 ? launch_wino_vs64<1>(a, s, 1, hd) : launch_wino_vs64<2>(a, s, 1, hd);
+    if (n2 == 1) return launch_wino_vs64<1>(a, s, 1, hd);
+    if (n2 == 2) return launch_wino_vs64<2>(a, s, 1, hd);
+    if (n2 <= 32) return launch_wino_vs64<0, 1>(a, s, 1, hd);          // MFMA phase for all outputs (hm_hp: 17)
+    if (n2 == 33) return launch_wino_vs64<1, 1>(a, s, 1, hd);
+    return launch_wino_vs64<2, 1>(a, s, 1, hd);                         // hps: 32 through the MFMA phase + 2 on the register path
 }
 
 // a.w = Winograd-domain weights from cp_winograd_pack_f32.  Returns -1 when the shape is not eligible.

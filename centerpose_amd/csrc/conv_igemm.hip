@@ -200,11 +200,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t s)
     auto kern = igemm_conv_kernel<BM, BN, WAVES_M, WAVES_N, MF, STEM>;
     if (a.ldw % BN != 0) { cp_set_error("conv2d: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
     const int smem = a.outNCHW ? T::SMEM : T::NHWC_BYTES;
-    static bool attr = false;
-    if (!attr && smem > 64 * 1024) {
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, T::SMEM > T::NHWC_BYTES ? T::SMEM : T::NHWC_BYTES);
-        attr = true;
-    }
+    static CpLdsGuard guard;
+    constexpr int smem_max = T::SMEM > T::NHWC_BYTES ? T::SMEM : T::NHWC_BYTES;
+    if (smem > 64 * 1024 && guard.need(smem_max))
+        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
     const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN) * (a.nsub > 1 ? a.nsub : 1);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
     cp_note_kernel("igemm_conv_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, WAVES_M, WAVES_N, MF, STEM ? "true" : "false");

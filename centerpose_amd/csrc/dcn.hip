@@ -20,20 +20,14 @@
 #define DCN_MAX_TAPS 9
 typedef float dcn_v2 __attribute__((ext_vector_type(2)));
 
-// KW = 16-deep k-steps gathered at once.  KW = 2: a (pixel, corner) gather covers 32 channels = one whole 128-byte
-// cache line (8 lanes x 16 B) instead of a 64-byte half: PMC shows 71 % of the gather's line accesses miss the 32 KB L1
-// and go to L2 (5 blocks per CU thrash it), and L2 -> L1 moves 128-byte lines, so half-line gathers waste half of the
-// fabric bandwidth this kernel is bound by (tools/micro/l1_gather.hip: 19 vs 32 TB/s useful for 64 B vs 128 B segments).
-// PF = 2: the gathers (and the weight slice) of k-step s+2 are issued during k-step s, i.e. they have a whole k-step of
-// MFMAs more to land before they are blended into LDS (PF = 1: half a k-step, 4 MFMAs = 256 cycles, less than an L2 hit
-// under load: PMC showed the waves parked on s_waitcnt / the barrier 28 % of the time).  Two register sets, loop unrolled
-// by two; no VMEM instruction sits inside a conditional (the waitcnt pass merges counters pessimistically at a join and would
-// wait for the loads it has just issued): the prefetch past the end re-reads the last k-step.
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, int KW, int PF>
+// One k-step = 16 input channels of one tap: 4 lanes (float4 quads) per pixel, 64 pixels per pass.  The gathers (and the
+// weight slice) of k-step s+1 are issued from inside the MFMA block of k-step s.  Variants measured and removed in round 3
+// (two-deep prefetch, full-line 32-channel gathers, 32-channel k-steps): DESIGN.md 7.3.
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF>
 __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs a)
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
-    constexpr int QL = 4 * KW;                      // lanes (float4 quads) per pixel
+    constexpr int QL = 4;                           // lanes (float4 quads) per pixel
     constexpr int PPP = IG_THREADS / QL;            // pixels per pass
     constexpr int ASL = BM / PPP;                   // gather slots per thread per step
     static_assert(ASL >= 1, "BM too small for this gather width");
@@ -41,8 +35,8 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     // records first, GEMM staging after; the NCHW epilogue reuses the whole region from the base
     float4* s_w = reinterpret_cast<float4*>(smem);                 // [taps][BM] corner weights * mask
     int* s_code = reinterpret_cast<int*>(s_w + DCN_MAX_TAPS * BM); // [taps][BM] base | dx<<29 | dy<<30
-    float* As0 = smem + DCN_MAX_TAPS * BM * 5;      // [2 buffers][KW][A_FLOATS]
-    float* Bs0 = As0 + 2 * KW * T::A_FLOATS;        // [2 buffers][KW][B_FLOATS]
+    float* As0 = smem + DCN_MAX_TAPS * BM * 5;      // [2 buffers][A_FLOATS]
+    float* Bs0 = As0 + 2 * T::A_FLOATS;             // [2 buffers][B_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int NT = a.ldw / BN;
@@ -110,9 +104,9 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < IgAcc<MF>::N; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.K / (IG_BK * KW);
+    const int nk = a.K / IG_BK;
     const int q = tid % QL;
-    float4 br[KW][T::B_SLOTS];
+    float4 br[T::B_SLOTS];
     float4 c00[ASL], c01[ASL], c10[ASL], c11[ASL], wq[ASL];
     int tap = 0, cl = 0;
     __syncthreads();
@@ -144,7 +138,7 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
             c11[s] = ig_ldg4(reinterpret_cast<const float*>(xs + o11[s]));
         }
     };
-    auto advance = [&]() __attribute__((always_inline)) { cl += IG_BK * KW; if (cl >= C) { cl = 0; ++tap; } };
+    auto advance = [&]() __attribute__((always_inline)) { cl += IG_BK; if (cl >= C) { cl = 0; ++tap; } };
     auto store_a = [&](float* As) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < ASL; ++s) {
@@ -159,219 +153,52 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
             const dcn_v2 hi = __builtin_elementwise_fma(ww, (dcn_v2){c11[s].z, c11[s].w},
                               __builtin_elementwise_fma(wz, (dcn_v2){c10[s].z, c10[s].w},
                               __builtin_elementwise_fma(wy, (dcn_v2){c01[s].z, c01[s].w}, wx * (dcn_v2){c00[s].z, c00[s].w})));
-            *reinterpret_cast<float4*>(As + (q >> 2) * T::A_FLOATS + pl * IG_LDK + (q & 3) * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
+            *reinterpret_cast<float4*>(As + pl * IG_LDK + q * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
     };
 
-    auto load_b = [&](int ks) __attribute__((always_inline)) {
-#pragma unroll
-        for (int w = 0; w < KW; ++w) ig_load_b<T>(a, (ks * KW + w) * IG_BK, n0, tid, br[w]);
-    };
-    auto store_b = [&](float* Bs) __attribute__((always_inline)) {
-#pragma unroll
-        for (int w = 0; w < KW; ++w) ig_store_b<T>(Bs + w * T::B_FLOATS, tid, br[w]);
-    };
-    if constexpr (PF == 3) {
-        // FULL-LINE gathers: 8 lanes per (pixel, corner) fetch 32 channels = one whole 128-byte line, for TWO k-steps at once
-        // (PF = 1 fetches the two 64-byte halves of a line one k-step apart; in between the five resident blocks push ~80 KB
-        // through the 32 KB L1, so the second half misses again: PMC 70 % L1 miss, every line moved L2 -> L1 twice).  The
-        // LDS footprint stays one k-step per buffer: all lanes blend once per pair, lanes q < 4 (channels 0..15 of the pair)
-        // hand their float4 to LDS for the even k-step, lanes q >= 4 keep theirs in registers one k-step longer.  The gathers
-        // of pair P+1 are issued from inside the even k-step of pair P and consumed after its odd k-step: 1.5 k-steps of
-        // MFMAs to land instead of half of one.  No VMEM instruction sits inside a conditional (see PF = 2).
-        static_assert(KW == 1 && BM % 32 == 0, "full-line gather: 16-channel k-steps, 32 pixels per pass");
-        constexpr int S3 = BM / 32;
-        const int q3 = tid & 7, p3 = tid >> 3, half3 = q3 >> 2;
-        float4 G0[S3], G1[S3], G2[S3], G3[S3], W3[S3], BL[S3], BR[T::B_SLOTS];
-        unsigned a00[S3], a01[S3], a10[S3], a11[S3];
-        int gtap = 0, gcl = 0;                                   // next 32-channel pair to gather (saturates at the end)
-        auto gather = [&]() __attribute__((always_inline)) {
-            if (gcl == 0) {                                      // LDS + VALU only
-#pragma unroll
-                for (int s2 = 0; s2 < S3; ++s2) {
-                    const int pl = p3 + s2 * 32;
-                    const int code = s_code[gtap * BM + pl];
-                    W3[s2] = s_w[gtap * BM + pl];
-                    a00[s2] = (unsigned)(code & 0x1FFFFFFF) * pixb + (unsigned)q3 * 16u;
-                    a01[s2] = a00[s2] + (((unsigned)code >> 29) & 1u) * pixb;
-                    a10[s2] = a00[s2] + (((unsigned)code >> 30) & 1u) * rowb;
-                    a11[s2] = a10[s2] + (a01[s2] - a00[s2]);
-                }
-            }
-            const char* xs = reinterpret_cast<const char*>(x) + (size_t)gcl * 4;      // uniform
-#pragma unroll
-            for (int s2 = 0; s2 < S3; ++s2) {
-                G0[s2] = ig_ldg4(reinterpret_cast<const float*>(xs + a00[s2]));
-                G1[s2] = ig_ldg4(reinterpret_cast<const float*>(xs + a01[s2]));
-                G2[s2] = ig_ldg4(reinterpret_cast<const float*>(xs + a10[s2]));
-                G3[s2] = ig_ldg4(reinterpret_cast<const float*>(xs + a11[s2]));
-            }
-            if (gtap * C + gcl + 2 * IG_BK < a.K) { gcl += 2 * IG_BK; if (gcl >= C) { gcl = 0; ++gtap; } }
-        };
-        auto blend = [&]() __attribute__((always_inline)) {
-#pragma unroll
-            for (int s2 = 0; s2 < S3; ++s2) {
-                const float4 w = W3[s2];
-                const dcn_v2 wx = {w.x, w.x}, wy = {w.y, w.y}, wz = {w.z, w.z}, ww = {w.w, w.w};
-                const dcn_v2 lo = __builtin_elementwise_fma(ww, (dcn_v2){G3[s2].x, G3[s2].y},
-                                  __builtin_elementwise_fma(wz, (dcn_v2){G2[s2].x, G2[s2].y},
-                                  __builtin_elementwise_fma(wy, (dcn_v2){G1[s2].x, G1[s2].y}, wx * (dcn_v2){G0[s2].x, G0[s2].y})));
-                const dcn_v2 hi = __builtin_elementwise_fma(ww, (dcn_v2){G3[s2].z, G3[s2].w},
-                                  __builtin_elementwise_fma(wz, (dcn_v2){G2[s2].z, G2[s2].w},
-                                  __builtin_elementwise_fma(wy, (dcn_v2){G1[s2].z, G1[s2].w}, wx * (dcn_v2){G0[s2].z, G0[s2].w})));
-                BL[s2] = make_float4(lo.x, lo.y, hi.x, hi.y);
-            }
-        };
-        auto hand_over = [&](int half, float* As, float* Bs) __attribute__((always_inline)) {
-            if (half3 == half) {
-#pragma unroll
-                for (int s2 = 0; s2 < S3; ++s2)
-                    *reinterpret_cast<float4*>(As + (p3 + s2 * 32) * IG_LDK + (q3 & 3) * 4) = BL[s2];
-            }
-            ig_store_b<T>(Bs, tid, BR);
-        };
-        float* As1 = As0 + T::A_FLOATS; float* Bs1 = Bs0 + T::B_FLOATS;
-        ig_load_b<T>(a, 0, n0, tid, BR);
-        gather();
-        blend();
-        hand_over(0, As0, Bs0);
-        __syncthreads();
-#pragma unroll 1
-        for (int ks = 0; ks < nk; ks += 2) {
-            // even k-step: the weight slice first (vmcnt retires in order: the hand-over below then waits for it with the
-            // eight gathers still in flight), then the next pair's gathers
-            ig_compute<T, MF>(As0, Bs0, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
-                ig_load_b<T>(a, (ks + 1 < nk ? ks + 1 : nk - 1) * IG_BK, n0, tid, BR);
-                gather();
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            hand_over(1, As1, Bs1);
-            __syncthreads();
-            ig_compute<T, MF>(As1, Bs1, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
-                ig_load_b<T>(a, (ks + 2 < nk ? ks + 2 : nk - 1) * IG_BK, n0, tid, BR);
-            });
-            __builtin_amdgcn_sched_barrier(0);
-            blend();
-            hand_over(0, As0, Bs0);
-            __syncthreads();
+    load_a(); advance();
+    ig_load_b<T>(a, 0, n0, tid, br);
+    store_a(As0);
+    ig_store_b<T>(Bs0, tid, br);
+    __syncthreads();
+    int cur = 0;
+    for (int ks = 0; ks < nk; ++ks) {
+        const bool more = ks + 1 < nk;
+        // the next step's gathers are issued from inside the MFMA block (half-way through the k-step)
+        ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
+            if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
+        });
+        // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
+        // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) {
+            store_a(As0 + (cur ^ 1) * T::A_FLOATS);
+            ig_store_b<T>(Bs0 + (cur ^ 1) * T::B_FLOATS, tid, br);
         }
-    } else if constexpr (PF == 2) {
-        static_assert(KW == 1, "two-deep prefetch is built for 16-channel k-steps");
-        float4 C0[2][ASL], C1[2][ASL], C2[2][ASL], C3[2][ASL], W[2][ASL], BR[2][T::B_SLOTS];
-        int ltap = 0, lcl = 0;                                   // position of the next k-step to gather (saturates at the end)
-        auto gather = [&](int set, int ksb) __attribute__((always_inline)) {
-            if (lcl == 0) {                                      // LDS + VALU only
-#pragma unroll
-                for (int s2 = 0; s2 < ASL; ++s2) {
-                    const int pl = tid / QL + s2 * PPP;
-                    const int code = s_code[ltap * BM + pl];
-                    wq[s2] = s_w[ltap * BM + pl];
-                    o00[s2] = (unsigned)(code & 0x1FFFFFFF) * pixb + (unsigned)q * 16u;
-                    o01[s2] = o00[s2] + (((unsigned)code >> 29) & 1u) * pixb;
-                    o10[s2] = o00[s2] + (((unsigned)code >> 30) & 1u) * rowb;
-                    o11[s2] = o10[s2] + (o01[s2] - o00[s2]);
-                }
-            }
-            const char* xs = reinterpret_cast<const char*>(x) + (size_t)lcl * 4;      // uniform
-#pragma unroll
-            for (int s2 = 0; s2 < ASL; ++s2) {
-                C0[set][s2] = ig_ldg4(reinterpret_cast<const float*>(xs + o00[s2]));
-                C1[set][s2] = ig_ldg4(reinterpret_cast<const float*>(xs + o01[s2]));
-                C2[set][s2] = ig_ldg4(reinterpret_cast<const float*>(xs + o10[s2]));
-                C3[set][s2] = ig_ldg4(reinterpret_cast<const float*>(xs + o11[s2]));
-                W[set][s2] = wq[s2];
-            }
-            ig_load_b<T>(a, (ksb < nk ? ksb : nk - 1) * IG_BK, n0, tid, BR[set]);
-            if (ltap * C + lcl + IG_BK < a.K) { lcl += IG_BK; if (lcl >= C) { lcl = 0; ++ltap; } }
-        };
-        auto blend_store = [&](int set, float* As, float* Bs) __attribute__((always_inline)) {
-#pragma unroll
-            for (int s2 = 0; s2 < ASL; ++s2) {
-                const int pl = tid / QL + s2 * PPP;
-                const float4 w = W[set][s2];
-                const dcn_v2 wx = {w.x, w.x}, wy = {w.y, w.y}, wz = {w.z, w.z}, ww = {w.w, w.w};
-                const dcn_v2 lo = __builtin_elementwise_fma(ww, (dcn_v2){C3[set][s2].x, C3[set][s2].y},
-                                  __builtin_elementwise_fma(wz, (dcn_v2){C2[set][s2].x, C2[set][s2].y},
-                                  __builtin_elementwise_fma(wy, (dcn_v2){C1[set][s2].x, C1[set][s2].y}, wx * (dcn_v2){C0[set][s2].x, C0[set][s2].y})));
-                const dcn_v2 hi = __builtin_elementwise_fma(ww, (dcn_v2){C3[set][s2].z, C3[set][s2].w},
-                                  __builtin_elementwise_fma(wz, (dcn_v2){C2[set][s2].z, C2[set][s2].w},
-                                  __builtin_elementwise_fma(wy, (dcn_v2){C1[set][s2].z, C1[set][s2].w}, wx * (dcn_v2){C0[set][s2].z, C0[set][s2].w})));
-                *reinterpret_cast<float4*>(As + pl * IG_LDK + (q & 3) * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
-            }
-            ig_store_b<T>(Bs, tid, BR[set]);
-        };
-        // one k-step: MFMAs on buffer `cur`, gathers of k-step ks+2 into register set `lset` from inside the MFMA block,
-        // then k-step ks+1 (register set lset^1, loaded one iteration ago) is blended into the other buffer
-        auto iter = [&](int ks, int cur, int lset) __attribute__((always_inline)) {
-            ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc,
-                              [&]() __attribute__((always_inline)) { gather(lset, ks + 2); });
-            __builtin_amdgcn_sched_barrier(0);
-            blend_store(lset ^ 1, As0 + (cur ^ 1) * T::A_FLOATS, Bs0 + (cur ^ 1) * T::B_FLOATS);
-            __syncthreads();
-        };
-        gather(0, 0);
-        gather(1, 1);
-        blend_store(0, As0, Bs0);
         __syncthreads();
-#pragma unroll 1
-        for (int ks = 0; ks < nk; ks += 2) {
-            iter(ks, 0, 0);
-            if (ks + 1 < nk) iter(ks + 1, 1, 1);
-        }
-    } else {
-        load_a(); advance();
-        load_b(0);
-        store_a(As0);
-        store_b(Bs0);
-        __syncthreads();
-        int cur = 0;
-        for (int ks = 0; ks < nk; ++ks) {
-            const bool more = ks + 1 < nk;
-            const float* Ac = As0 + cur * KW * T::A_FLOATS;
-            const float* Bc = Bs0 + cur * KW * T::B_FLOATS;
-            auto prefetch = [&]() __attribute__((always_inline)) { if (more) { load_a(); advance(); load_b(ks + 1); } };
-            // the next step's gathers are issued from inside the MFMA block (between the two k-steps, or half-way through one)
-            if constexpr (KW == 1) ig_compute<T, MF>(Ac, Bc, wm0, wn0, lane, acc, prefetch);
-            else {
-                ig_compute<T, MF>(Ac, Bc, wm0, wn0, lane, acc);
-                __builtin_amdgcn_sched_barrier(0);
-                prefetch();
-                __builtin_amdgcn_sched_barrier(0);
-                ig_compute<T, MF>(Ac + T::A_FLOATS, Bc + T::B_FLOATS, wm0, wn0, lane, acc);
-            }
-            // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
-            // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
-            __builtin_amdgcn_sched_barrier(0);
-            if (more) {
-                store_a(As0 + (cur ^ 1) * KW * T::A_FLOATS);
-                store_b(Bs0 + (cur ^ 1) * KW * T::B_FLOATS);
-            }
-            __syncthreads();
-            cur ^= 1;
-        }
+        cur ^= 1;
     }
     ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc);
 }
 
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, int KW = 1, int PF = 1>
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF>
 static int launch_dcn(const ConvArgs& a, hipStream_t s)
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
-    auto kern = dcn_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MF, KW, PF>;
-    if (a.srcC[0] % (IG_BK * KW) != 0) { cp_set_error("dcn: C=%d is not a multiple of %d", a.srcC[0], IG_BK * KW); return 1; }
+    auto kern = dcn_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MF>;
+    if (a.srcC[0] % IG_BK != 0) { cp_set_error("dcn: C=%d is not a multiple of %d", a.srcC[0], IG_BK); return 1; }
     if (a.ldw % BN != 0) { cp_set_error("dcn: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
-    const int main_bytes = KW * T::MAIN_BYTES + DCN_MAX_TAPS * BM * 20;
+    const int main_bytes = T::MAIN_BYTES + DCN_MAX_TAPS * BM * 20;
     const int epi = a.outNCHW ? T::EPI_BYTES : T::EPV_BYTES;
     const int smem = epi > main_bytes ? epi : main_bytes;
-    static bool attr = false;
-    if (!attr && smem > 64 * 1024) {
+    static CpLdsGuard guard;
+    if (smem > 64 * 1024 && guard.need(smem))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        attr = true;
-    }
     const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
-    cp_note_kernel("dcn_igemm_kernel<%d, %d, %d, %d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N, MF, KW, PF);
+    cp_note_kernel("dcn_igemm_kernel<%d, %d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N, MF);
     return 0;
 }
 
@@ -430,11 +257,7 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
         case 64064: rc = launch_dcn<64, 64, 2, 2, 32>(a, s); break;
         case 64032: rc = launch_dcn<64, 32, 4, 1, 16>(a, s); break;
         case 64128: rc = launch_dcn<64, 128, 2, 2, 32>(a, s); break;
-        case 2064064: rc = launch_dcn<64, 64, 2, 2, 32, 2>(a, s); break;      // 32-channel (full cache line) gathers
         case 6064128: rc = (d->ldw % 128 == 0) ? launch_dcn<64, 128, 2, 2, 32>(a, s) : launch_dcn<64, 64, 2, 2, 32>(a, s); break;
-        case 5064064: rc = launch_dcn<64, 64, 2, 2, 32, 1, 2>(a, s); break;     // two-deep gather prefetch
-        case 5064128: rc = (d->ldw % 128 == 0) ? launch_dcn<64, 128, 2, 2, 32, 1, 2>(a, s) : launch_dcn<64, 64, 2, 2, 32, 1, 2>(a, s); break;
-        case 7064064: rc = (d->C % 32 == 0) ? launch_dcn<64, 64, 2, 2, 32, 1, 3>(a, s) : launch_dcn<64, 64, 2, 2, 32>(a, s); break;   // full-line gathers
         default: CP_CHECK_ARG(false, "dcn_v2: unsupported tile %d (ldw=%d)", tile, d->ldw);
     }
     if (rc) return rc;

@@ -299,13 +299,12 @@ extern "C" int cp_decode_topk_f32(const float* heat, const float* hm_hp, int B, 
     const int chunk = (cp_cdiv(nbig, nchunks) + 3) & ~3;
     const int nmax = chunk;
     const size_t lds = (size_t)nmax * 4 + 2 * TK_MAX_K * 8 + 256 * 4 + TK_WAVES * 4 + 16;
-    static size_t lds_reserved[2] = {0, 0};   // one device per process (one rank per GPU)
+    static CpLdsGuard lds_reserved[2];        // per (instantiation, device)
     const int ck = nchunks > 1;
-    if (lds > lds_reserved[ck]) {
+    if (lds_reserved[ck].need((int)lds)) {
         hipError_t e = hipFuncSetAttribute(ck ? (const void*)nms_topk_kernel<true> : (const void*)nms_topk_kernel<false>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { cp_set_error("decode: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return 2; }
-        lds_reserved[ck] = lds;
     }
     hipStream_t s = (hipStream_t)stream;
     if (ck) hipLaunchKernelGGL(nms_topk_kernel<true>, dim3(B * (1 + J)), dim3(TK_THREADS), lds, s, heat, hm_hp, cat, J, H, W, K, P,

@@ -119,11 +119,10 @@ static int launch_stem(const float* x, const float* w, const float* scale, const
     const int Ho = (H + 6 - 7) / S + 1, Wo = (W + 6 - 7) / S + 1;
     const int smem = (((3 * PH * PW + 3) & ~3) + S7_STEPS * NOUT * IG_LDK) * 4;
     auto kern = stem7x7_kernel<NOUT, S, TH, TW>;
-    static bool attr = false;
-    if (!attr && smem > 64 * 1024) {
+    static CpLdsGuard guard;
+    if (smem > 64 * 1024 && guard.need(smem)) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) { cp_set_error("stem7x7: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
-        attr = true;
     }
     const int tilesX = cp_cdiv(Wo, TW), tilesY = cp_cdiv(Ho, TH);
     hipLaunchKernelGGL(kern, dim3((unsigned)(B * tilesX * tilesY)), dim3(IG_THREADS), smem, s, x, w, scale, shift, out, B, H, W, Ho,

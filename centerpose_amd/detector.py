@@ -209,6 +209,7 @@ class MultiPoseDetector(BaseDetector):
                 and not loss.MSE_LOSS and hasattr(self.model, "process")):
             # no stage timing asked for and nothing to do between forward and decode: both in ONE graph replay (the peak
             # extraction overlaps the last head convolutions).  `run()` keeps the two-stage form for its 'net' / 'dec' timers.
+            # `dets` is a fresh tensor on both paths (the reference returns one); `outputs` are the plan's static buffers.
             with torch.no_grad():
                 outputs, dets = self.model.process(images, self.cfg.TEST.TOPK)
             return outputs, dets

@@ -74,13 +74,20 @@ class DetsGatherer:
     """The step's one collective on a SIDE stream: `submit(dets)` enqueues the all-gather of this step's
     detections behind the decode that produced them and returns at once, so the next batch's backbone replay overlaps the
     (latency-bound, ~358 KB per rank) exchange over xGMI; `collect()` makes the current stream wait for the oldest
-    outstanding gather and returns its [B_global, K, D] tensor.  One step of pipelining; world 1 is a pass-through."""
+    outstanding gather and returns its [B_global, K, D] tensor.  One step of pipelining; world 1 is a pass-through.
+    `submit` must be given a tensor the producer will NOT overwrite before `collect` (the exchange reads it asynchronously):
+    `MultiPoseDetector.process` / `BackBoneWithHead.process` return such a private copy; a raw `Engine.dets` buffer must be
+    cloned first (bench.py does).  `last_wait_ms()` reports how long the last `collect` left the compute stream waiting."""
 
-    def __init__(self, global_batch=None):
+    def __init__(self, global_batch=None, time_waits=False):
         self.global_batch = global_batch
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.side = torch.cuda.Stream() if self.active and torch.cuda.is_available() and dist.get_backend() == "nccl" else None
         self.pending = []
+        # time_waits: bracket every collect()'s wait with two events on the compute stream -> `exposed_wait_ms()`: the time
+        # the compute stream sat waiting for an exchange, i.e. what the side-stream overlap did NOT hide
+        self.time_waits = time_waits and self.side is not None
+        self._waits = []
 
     def submit(self, dets):
         if self.side is None:
@@ -97,6 +104,43 @@ class DetsGatherer:
     def collect(self):
         out, done = self.pending.pop(0)
         if done is not None:
-            torch.cuda.current_stream().wait_event(done)
-            out.record_stream(torch.cuda.current_stream())
+            cur = torch.cuda.current_stream()
+            if self.time_waits:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_event(done)
+                e1.record(cur)
+                self._waits.append((e0, e1))
+            else:
+                cur.wait_event(done)
+            out.record_stream(cur)
         return out
+
+    def exposed_wait_ms(self):
+        """(total, max) milliseconds the compute stream waited inside collect() since the last call (needs time_waits and a
+        device synchronisation by the caller); (0.0, 0.0) when nothing was timed."""
+        w = [a.elapsed_time(b) for a, b in self._waits]
+        self._waits = []
+        return (sum(w), max(w)) if w else (0.0, 0.0)
+
+
+def check_gathered(gathered, local, global_batch):
+    """Every rank must hold the SAME gathered detections, and its own shard must sit at its `shard_range` slot bit for bit.
+    Exchanges one 64-bit checksum per rank (sum of the float bit patterns, position-weighted so a permutation of images is
+    caught).  Returns (ok, checksum, message); collective: call on every rank."""
+    world, rank = dist.get_world_size(), dist.get_rank()
+    lo, hi = shard_range(global_batch, rank, world)
+    own_ok = tuple(gathered.shape[1:]) == tuple(local.shape[1:]) and gathered.shape[0] == global_batch and \
+        bool(torch.equal(gathered[lo:hi].cpu(), local.cpu()))
+    bits = gathered.detach().contiguous().cpu().view(torch.int32).to(torch.int64).reshape(gathered.shape[0], -1)
+    weight = torch.arange(1, bits.shape[0] + 1, dtype=torch.int64).reshape(-1, 1)
+    csum = int(((bits * weight).sum() % (1 << 61)).item())
+    dev = gathered.device if dist.get_backend() == "nccl" else torch.device("cpu")
+    mine = torch.tensor([csum, 1 if own_ok else 0], dtype=torch.int64, device=dev)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    sums, oks = [int(v[0].item()) for v in allv], [int(v[1].item()) for v in allv]
+    ok = len(set(sums)) == 1 and all(oks)
+    msg = "ok: %d ranks hold identical gathered dets (checksum %x), every shard at its slot" % (world, csum) if ok else \
+        "MISMATCH: checksums %s, own-shard-ok %s" % ([hex(s) for s in sums], oks)
+    return ok, csum, msg

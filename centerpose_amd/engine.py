@@ -9,6 +9,7 @@ allocation and no host synchronisation on the hot path.
 Replaces ``BackBoneWithHead.forward`` (lib/models/model.py:57-59) for dla_34 / res_50 / hrnet.
 """
 import os
+import warnings
 import weakref
 
 import torch
@@ -307,24 +308,6 @@ class PlanBuilder(nets.Graph):
         return outs
 
 
-class _DagGraph:
-    """Owner of a cp_graph handle with torch.cuda.CUDAGraph's `replay()`."""
-
-    def __init__(self, handle):
-        self.h = handle
-
-    def replay(self):
-        _lib.check(_lib.lib().cp_graph_launch(self.h, _lib.stream()), "cp_graph_launch")
-
-    def __del__(self):
-        try:
-            if self.h:
-                _lib.lib().cp_graph_destroy(self.h)
-                self.h = None
-        except Exception:
-            pass
-
-
 def list_schedule(deps, durations, nstreams=2):
     """List scheduling of a DAG on `nstreams` in-order streams.  deps[i] = indices (< i) launch i must follow, durations[i] its
     time.  Priority = b-level (longest path from the launch to the end of the graph); the (ready launch, stream) pair that can
@@ -391,6 +374,7 @@ class Engine:
         self.flops_per_image = pb.flops
         self.activation_bytes = pb.bytes_alloc
         self.graph = None
+        self.capture_mode = None       # how the hipGraph was captured: "2-stream" / "single-stream" / "single-stream-fallback"
         self.use_graph = use_graph
         self.dets, self.decode_k = None, None
         if decode_k:
@@ -531,50 +515,11 @@ class Engine:
         # streams / events must outlive the capture (destroying a capturing stream before hipStreamEndCapture crashes)
         self._capture_refs = (streams, events, fork)
 
-    def build_dag_graph(self, edges=None):
-        """hipGraph with one node per launch and explicit edges from `dependencies()` (csrc/graph_builder.cpp): the whole
-        DAG instead of what two capture streams can express.  `edges`: use these predecessor lists instead (e.g. the chains +
-        cross edges of an N-stream schedule, tools/sched_try.py).  Returns a `_DagGraph` with `.replay()`."""
-        import ctypes
-        L = _lib.lib()
-        L.cp_graph_stream.restype = ctypes.c_void_p
-        deps = self.dependencies() if edges is None else edges
-        # transitive reduction: an edge j -> i is dropped when i already follows j through another predecessor (every edge
-        # that crosses executor streams is an event wait at replay time)
-        n = len(deps)
-        reach = [set() for _ in range(n)]                 # all ancestors
-        red = []
-        for i in range(n):
-            keep = []
-            for j in sorted(deps[i], reverse=True):
-                if not any(j in reach[k] for k in keep):
-                    keep.append(j)
-            for j in deps[i]:
-                reach[i].add(j)
-                reach[i] |= reach[j]
-            red.append(sorted(keep))
-        deps = red
-        g = ctypes.c_void_p()
-        _lib.check(L.cp_graph_create(ctypes.byref(g)), "cp_graph_create")
-        try:
-            cap = ctypes.c_void_p(L.cp_graph_stream(g))
-            for i, (_, _, _, launch) in enumerate(self.launches):
-                _lib.check(L.cp_graph_begin_node(g), "cp_graph_begin_node")
-                launch.run(cap)
-                d = (ctypes.c_int * max(1, len(deps[i])))(*deps[i])
-                nid = ctypes.c_int(-1)
-                _lib.check(L.cp_graph_end_node(g, d, len(deps[i]), ctypes.byref(nid)), "cp_graph_end_node")
-                assert nid.value == i
-            _lib.check(L.cp_graph_instantiate(g), "cp_graph_instantiate")
-        except Exception:
-            L.cp_graph_destroy(g)
-            raise
-        return _DagGraph(g)
-
     def capture(self):
         """Capture the whole schedule into one hipGraph (launch-bound inner loop -> one replay).  With
-        `self.nstreams > 1` (CP_STREAMS, default 2) independent branches are captured on parallel streams;
-        CP_GRAPH=dag builds the graph node by node from the data dependencies instead (`build_dag_graph`)."""
+        `self.nstreams > 1` (CP_STREAMS, default 2) independent branches are captured on parallel streams.  A failed
+        two-stream capture falls back to one stream LOUDLY: a RuntimeWarning, and `self.capture_mode` says
+        "single-stream-fallback" (bench.py prints it) -- the fallback costs 1-10 % and must not go unnoticed."""
         s = torch.cuda.Stream(device=self.device)
         s.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(s):
@@ -586,10 +531,7 @@ class Engine:
         # HRNet graphs - not for ResNet-50 or a minimal reproducer - so the default stays at two.)
         nstreams = getattr(self, "nstreams", None) or int(os.environ.get("CP_STREAMS", "2"))
         g = None
-        if os.environ.get("CP_GRAPH", "") == "dag":
-            self.graph = self.build_dag_graph()
-            self.stream_of_launch = [0] * len(self.launches)
-            return
+        self.capture_mode = "single-stream"
         if nstreams > 1:
             if getattr(self, "stream_plan", None) is None and nstreams == 2 and os.environ.get("CP_SCHED", "1") != "0":
                 self.schedule()
@@ -598,10 +540,16 @@ class Engine:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                     self._run_branches(s, nstreams, deps, getattr(self, "stream_plan", None))
-            except RuntimeError:                 # a failed multi-stream capture must not take the engine down
+                self.capture_mode = "%d-stream" % nstreams
+            except RuntimeError as e:            # a failed multi-stream capture must not take the engine down -- but say so
                 g = None
                 self._capture_refs = None
+                self.capture_mode = "single-stream-fallback"
                 torch.cuda.synchronize(self.device)
+                warnings.warn("centerpose_amd: %d-stream hipGraph capture failed (%s); falling back to a single-stream capture "
+                              "(slower by 1-10 %%)" % (nstreams, str(e).splitlines()[0] if str(e) else type(e).__name__), RuntimeWarning)
+                if os.environ.get("CP_STRICT_CAPTURE", "0") != "0":
+                    raise
         if g is None:
             g = torch.cuda.CUDAGraph()
             # thread_local: a collective library's watchdog thread (RCCL under torchrun) must not invalidate the capture

@@ -75,39 +75,49 @@ class BackBoneWithHead:
 
     def process(self, x, K=100):
         """forward + multi_pose_decode as ONE hipGraph replay (engine built with the decode inside its schedule):
-        -> ([hm, wh, hps, reg, hm_hp, hp_offset], dets [B, K, 56]); static buffers, overwritten by the next call."""
+        -> ([hm, wh, hps, reg, hm_hp, hp_offset], dets [B, K, 56]).  `dets` is a FRESH tensor owned by the caller, like the
+        reference's (decode.py:305-307 returns a torch.cat result): a stream-ordered copy of the plan's static buffer
+        (22.4 KB per image), so collecting dets over several calls or handing them to `dist.DetsGatherer.submit` is safe.
+        The six head maps are the plan's static output buffers (3.8 MB per image), overwritten by the next call -- the same
+        contract as `forward`."""
         B, _, H, W = x.shape
-        return self.engine_for(B, H, W, decode_k=K).process(x)
+        outs, dets = self.engine_for(B, H, W, decode_k=K).process(x)
+        return outs, dets.clone()
 
 
 def create_model(arch, head_conv, cfg):
     return BackBoneWithHead(arch, head_conv, cfg)
 
 
+def reconcile_state_dict(loaded, wanted, log=print):
+    """The checkpoint-vs-model key reconciliation of model.py:82-101 as a pure function: -> the state_dict to load.
+    Every key of `wanted` (the model's own tensors) appears in the result: the loaded tensor when name and shape agree, else
+    the model's tensor (shape mismatch: "Skip loading"; absent: "No param").  Checkpoint keys the model does not have are
+    dropped ("Drop parameter").  Messages keep the reference's wording so logs stay greppable."""
+    hint = "If you see this, your model does not fully load the pre-trained weight."
+    out = {}
+    for k in (k for k in loaded if k not in wanted):
+        log("Drop parameter {}.".format(k) + hint)
+    for k, own in wanted.items():
+        got = loaded.get(k)
+        if got is None:
+            log("No param {}.".format(k) + hint)
+        elif got.shape != own.shape:
+            log("Skip loading parameter {}, required shape{}, loaded shape{}. {}".format(k, own.shape, got.shape, hint))
+            got = None
+        out[k] = own if got is None else got
+    return out
+
+
 def load_model(model, model_path, optimizer=None, resume=False, lr=None, lr_step=None):
-    """model.py:67-120 (inference subset): strips 'module.', keeps the model's tensor on a shape
-    mismatch, fills missing keys from the model, ignores unknown keys."""
-    checkpoint = torch.load(model_path, map_location=lambda storage, loc: storage)
-    print("loaded {}, epoch {}".format(model_path, checkpoint["epoch"]))
-    state_dict = engine.normalize_state_dict(checkpoint["state_dict"])
-    model_state_dict = model.state_dict()
-    msg = "If you see this, your model does not fully load the pre-trained weight."
-    for k in list(state_dict):
-        if k in model_state_dict:
-            if state_dict[k].shape != model_state_dict[k].shape:
-                print("Skip loading parameter {}, required shape{}, loaded shape{}. {}".format(
-                    k, model_state_dict[k].shape, state_dict[k].shape, msg))
-                state_dict[k] = model_state_dict[k]
-        else:
-            print("Drop parameter {}.".format(k) + msg)
-            del state_dict[k]
-    for k in model_state_dict:
-        if k not in state_dict:
-            print("No param {}.".format(k) + msg)
-            state_dict[k] = model_state_dict[k]
-    model.load_state_dict(state_dict, strict=False)
+    """model.py:67-120, inference subset: {'epoch', 'state_dict'} checkpoint, optional 'module.' prefix stripped
+    (`engine.normalize_state_dict`), keys reconciled against the model (`reconcile_state_dict`)."""
     if optimizer is not None:
         raise NotImplementedError("optimizer resume is training-only (out of scope for the inference hot path)")
+    checkpoint = torch.load(model_path, map_location="cpu")
+    print("loaded {}, epoch {}".format(model_path, checkpoint["epoch"]))
+    model.load_state_dict(reconcile_state_dict(engine.normalize_state_dict(checkpoint["state_dict"]), model.state_dict()),
+                          strict=False)
     return model
 
 

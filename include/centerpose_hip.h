@@ -205,22 +205,6 @@ int cp_plan_destroy(cp_plan* plan);
 /* stream-ordered device-to-device copy (for callers that keep a plan's outputs beyond the next forward) */
 int cp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 
-/* ---- hipGraph assembled from a launch schedule's data dependencies ------------------------------
- * Stream capture follows streams; capturing on more than two crashes hipStreamEndCapture on ROCm 7.2 for the DLA / HRNet
- * schedules.  cp_graph_* captures every launch alone (cp_graph_begin_node; enqueue ONE launch of this library on
- * cp_graph_stream(); cp_graph_end_node with the ids of the launches it must follow) and links the resulting child graphs with
- * explicit edges, so the instantiated graph carries the whole DAG (HRNet's parallel resolutions, IDAUp projections, the six
- * head branches of lib/models/heads/keypoint.py:14-42).  cp_graph_launch replays it on `stream`.  Measured: correct but SLOWER than
- * the two-stream capture on ROCm 7.2 (hrnet B=8 1 022 vs 1 136 img/s, dla_34 1 795 vs 1 831) -- selectable with CP_GRAPH=dag, not default. */
-typedef struct cp_graph cp_graph;
-int cp_graph_create(cp_graph** out);
-void* cp_graph_stream(cp_graph* g);
-int cp_graph_begin_node(cp_graph* g);
-int cp_graph_end_node(cp_graph* g, const int* deps, int ndeps, int* node_id);
-int cp_graph_instantiate(cp_graph* g);
-int cp_graph_launch(cp_graph* g, void* stream);
-int cp_graph_destroy(cp_graph* g);
-
 /* ---- host: soft-NMS of merged results --------------------------------------------------------
  * Replaces soft_nms_39 (lib/external/nms.pyx:172-275; called from multi_pose.py:76-77).
  * boxes: HOST float32 [N,56], modified in place with the reference's quirks; keep: HOST int[N] or NULL. */

@@ -2,7 +2,7 @@
  * (lib/external/nms.pyx:172-275), the only variant the detector calls
  * (lib/detectors/multi_pose.py:76-77: soft_nms_39(results, Nt=0.5, method=2)).
  * The Cython source does not compile with Cython 3 / numpy 2 (np.int_t, nms.pyx:32), so parity is
- * pinned by hand-worked cases in tests/test_soft_nms.py.  "parity unpinned" by reference vectors.
+ * pinned by hand-worked cases in tests/test_host_logic.py (test_soft_nms_39_*).  "parity unpinned" by reference vectors.
  *
  * boxes: [N,56] float32 rows, modified IN PLACE exactly like the reference: the max-score row is
  * swapped into position i (columns 0..38 only, nms.pyx:214-235 -- the 17 keypoint scores 39..55

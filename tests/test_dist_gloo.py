@@ -44,6 +44,16 @@ def _worker(rank, world, port, batches, q):
         gat.submit(t)
         c = gat.collect()
         assert torch.equal(a, b) and torch.equal(a, c)
+        # bench.py --gather-check: identical gathered tensors everywhere + every shard at its slot ...
+        ok, csum, msg = cpd.check_gathered(a, t, global_batch)
+        assert ok and msg.startswith("ok: 2 ranks"), msg
+        # ... and a single rank whose copy differs is seen by EVERY rank
+        bad = a.clone()
+        if rank == 1:
+            bad[0, 0, 0] += 1.0
+        ok2, _, msg2 = cpd.check_gathered(bad, t, global_batch)
+        assert not ok2 and "MISMATCH" in msg2, msg2
+        assert gat.exposed_wait_ms() == (0.0, 0.0)               # nothing is timed without a side stream (gloo)
         out.append(a.numpy())
     dist.barrier()
     q.put((rank, out))

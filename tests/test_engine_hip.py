@@ -87,11 +87,16 @@ def test_process_end_to_end(arch):
     sc = ref[..., 4].astype(np.float64)
     gap = np.minimum(np.abs(np.diff(sc, axis=1, prepend=np.inf)), np.abs(np.diff(sc, axis=1, append=-np.inf)))
     stable = gap > 2e-4          # 2 x the observed fp32 forward error bound (1e-4)
-    assert stable.mean() > 0.5
+    close = np.isclose(dets[..., 5:39][stable], ref[..., 5:39][stable], atol=2e-2)
+    # shown with `pytest -s` / on failure: a regression from 99 % to 51 % stable must be visible, not just still-passing
+    print("%s: %d / %d detections compared (stable fraction %.3f); max |d score| %.2e, max |d box| %.2e, keypoint coords "
+          "within 2e-2: %.4f" % (arch, int(stable.sum()), stable.size, stable.mean(),
+                                 np.abs(dets[..., 4][stable] - ref[..., 4][stable]).max(),
+                                 np.abs(dets[..., :4][stable] - ref[..., :4][stable]).max(), close.mean()))
+    assert stable.mean() > 0.5, "only %.3f of the detections have a score gap > 2e-4" % stable.mean()
     assert np.allclose(dets[..., 4][stable], ref[..., 4][stable], atol=1e-3)
     assert np.allclose(dets[..., :4][stable], ref[..., :4][stable], atol=2e-2)
     # keypoint coordinates: allow rare accept/reject flips at a threshold
-    close = np.isclose(dets[..., 5:39][stable], ref[..., 5:39][stable], atol=2e-2)
     assert close.mean() > 0.995
 
 
@@ -349,29 +354,20 @@ def test_detector_process_one_replay_equals_two_stage():
     det = detector.MultiPoseDetector(cfg)
     x = synth.make_images(1, 128, 128, seed=3).cuda()
     o1, d1 = det.process(x)
-    assert d1.data_ptr() == det.model.engine_for(1, 128, 128, decode_k=cfg.TEST.TOPK).dets.data_ptr()      # the one-replay path ran
+    eng = det.model._engines.get((1, 128, 128, cfg.TEST.TOPK))
+    assert eng is not None and eng.decode_k == cfg.TEST.TOPK                  # the one-replay path ran
+    assert d1.data_ptr() != eng.dets.data_ptr() and torch.equal(d1, eng.dets)  # ... and handed out a private copy
+    keep = d1
     o1, d1 = [t.clone() for t in o1], d1.clone()
+    det.process(synth.make_images(1, 128, 128, seed=4).cuda())                # the next call must not overwrite what the caller holds
+    torch.cuda.synchronize()
+    assert torch.equal(keep, d1) and not torch.equal(keep, eng.dets)
     o2, d2, t = det.process(x, return_time=True)
     torch.cuda.synchronize()
     assert all(torch.equal(p, q) for p, q in zip(o1, o2)) and torch.equal(d1, d2) and t > 0
     flip = detector.MultiPoseDetector(config.get_cfg("res_50", TEST__FLIP_TEST=True))
     with pytest.raises(ValueError):                 # the mirrored twin is missing: refuse instead of reading past the batch
         flip.process(x)
-
-
-def test_dag_graph_is_bit_identical(monkeypatch):
-    """CP_GRAPH=dag: the hipGraph assembled node by node from the data dependencies (csrc/graph_builder.cpp, transitively
-    reduced edges) replays the same bits as the eager schedule."""
-    from centerpose_amd import engine, synth
-    sd = synth.make_state_dict("hrnet")
-    x = synth.make_images(2, 128, 128).cuda()
-    ref = [t.clone() for t in engine.Engine("hrnet", sd, 2, 128, 128, use_graph=False)(x)]
-    monkeypatch.setenv("CP_GRAPH", "dag")
-    e = engine.Engine("hrnet", sd, 2, 128, 128, use_graph=True)
-    for _ in range(3):
-        out = e(x)
-    torch.cuda.synchronize()
-    assert isinstance(e.graph, engine._DagGraph) and all(torch.equal(a, b) for a, b in zip(ref, out))
 
 
 def test_full_size_batch_invariance_and_scaling_property(monkeypatch):
@@ -461,3 +457,55 @@ def test_buffer_reuse_is_bit_identical_and_smaller(monkeypatch):
         torch.cuda.synchronize()
         assert all(torch.equal(p, q) for p, q in zip(ref, out))
         assert e1.activation_bytes < 0.8 * big
+
+
+BENCH_LINE = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "bench_line.json")
+
+
+@pytest.mark.parametrize("arch,B", [("dla_34", 16), ("res_50", 8), ("hrnet", 8)])
+def test_timed_configuration_parity(arch, B):
+    """The configuration bench.py times, at its own batch: BASELINE.json configs[2] = dla_34 512x512 B=16 (also the
+    per-GPU shape of configs[3]); configs[1] = res_50 B=8; configs[4]'s per-GPU shape = hrnet B=8.  The engine comes from
+    `bench.make_engine` -- decode inside the schedule, critical-path two-stream hipGraph, fused head launches, the batch-dependent
+    tile choices of this size.  Reference side: MultiPoseDetector.process, lib/detectors/multi_pose.py:29-60.
+    (a) images 0, B/2-1, B-1 against the CPU oracle network: the north-star 1e-3 bar on every head;
+    (b) dets of ALL images bit-equal to the oracle decode of the engine's own head maps;
+    (c) dla_34 B=16: the kernel instantiations this engine dispatched to are exactly the ones in the committed bench line
+        (profiles/bench_line.json -> roofline.kernels), i.e. the tested kernels ARE the timed kernels;
+    (d) a second replay reproduces every bit."""
+    import json
+    import sys
+    from centerpose_amd import synth
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    eng = bench.make_engine(arch, B)
+    x = synth.make_images(B, seed=317)
+    outs, dets = eng.process(x.cuda())
+    torch.cuda.synchronize()
+    assert eng.capture_mode == "2-stream", eng.capture_mode
+    first = [t.clone() for t in outs] + [dets.clone()]
+    outs, dets = eng.process(x.cuda())                                                    # (d)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(first, list(outs) + [dets]))
+    o = [t.cpu().numpy() for t in outs]
+    want = decode_np.multi_pose_decode(o[0], o[1], o[2], o[3], o[4], o[5], K=100)          # (b)
+    assert dets.shape == (B, 100, 56) and np.array_equal(dets.cpu().numpy(), want)
+    sd = synth.make_state_dict(arch)
+    worst = {}
+    for i in sorted({0, B // 2 - 1, B - 1}):                                              # (a)
+        refs = nets_torch.forward(arch, sd, x[i:i + 1])
+        for n, got, r in zip(("hm", "wh", "hps", "reg", "hm_hp", "hp_offset"), outs, refs):
+            got, r = got[i:i + 1].cpu().double(), r.double()
+            if n in ("hm", "hm_hp"):
+                r = torch.sigmoid(r)                       # the plan sigmoids hm / hm_hp in the head epilogue (multi_pose.py:35-37)
+            tol = 1e-3 if n in ("hm", "hm_hp", "reg", "hp_offset") else 1e-3 * r.abs().max().item()
+            err = (got - r).abs().max().item()
+            worst[n] = max(worst.get(n, 0.0), err / tol)
+            assert err <= tol, "image %d %s: max err %.3e > %.3e" % (i, n, err, tol)
+    print("%s B=%d: worst error / tolerance per head: %s" % (arch, B, {k: round(v, 4) for k, v in worst.items()}))
+    kernels = sorted({l.kernel or l.fn for _, _, _, l in eng.launches})
+    print("kernel instantiations:", kernels)
+    if arch == "dla_34":                                                                   # (c)
+        assert os.path.exists(BENCH_LINE), "profiles/bench_line.json (the committed `python bench.py` line) is missing"
+        timed = sorted(json.load(open(BENCH_LINE))["roofline"]["kernels"])
+        assert kernels == timed, "tested kernels %s != timed kernels %s -- refresh profiles/bench_line.json" % (kernels, timed)

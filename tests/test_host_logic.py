@@ -224,3 +224,34 @@ def test_list_schedule_properties():
     # the longer branch goes first: 0 -> {1 (short), 2 (long)} -> 3
     order, assign, mk = list_schedule([[], [0], [0], [1, 2]], [1.0, 2.0, 3.0, 1.0], 2)
     assert mk == 5.0 and assign[1] != assign[2]
+
+
+def test_reconcile_state_dict_and_load_model(tmp_path, capsys):
+    """load_model's checkpoint contract (lib/models/model.py:67-101): 'module.' prefix stripped, a shape mismatch keeps the
+    model's own tensor, a key the model lacks is dropped, a key the checkpoint lacks is filled from the model -- each with the
+    reference's log line."""
+    from centerpose_amd import model as cpm
+
+    class Holder:
+        def __init__(self, sd):
+            self.sd, self.loaded = sd, None
+
+        def state_dict(self):
+            return self.sd
+
+        def load_state_dict(self, sd, strict=False):
+            self.loaded = sd
+
+    own = {"a.weight": torch.zeros(2, 3), "b.bias": torch.zeros(4), "c.weight": torch.zeros(5)}
+    ckpt = {"module.a.weight": torch.ones(2, 3), "module.b.bias": torch.ones(7), "module.extra": torch.ones(1)}
+    path = str(tmp_path / "ck.pth")
+    torch.save({"epoch": 12, "state_dict": ckpt}, path)
+    h = cpm.load_model(Holder(own), path)
+    assert set(h.loaded) == set(own)
+    assert torch.equal(h.loaded["a.weight"], torch.ones(2, 3))        # taken from the checkpoint
+    assert h.loaded["b.bias"] is own["b.bias"]                        # shape mismatch: the model's tensor stays
+    assert h.loaded["c.weight"] is own["c.weight"]                    # absent from the checkpoint
+    out = capsys.readouterr().out
+    assert "epoch 12" in out and "Skip loading parameter b.bias" in out and "Drop parameter extra." in out and "No param c.weight." in out
+    with pytest.raises(NotImplementedError):
+        cpm.load_model(Holder(own), path, optimizer=object())
