@@ -172,7 +172,7 @@ struct WgHead {
 template <int N2, int MM>
 __device__ __forceinline__ void wg_output_tile_head(const ConvArgs& a, const WgHead& hd, float* red, const f32x16 (&acc)[4], int xi, int h,
                                                     int m, int tid, int yb, int x0, int tile, float (&acc2)[2][2][N2 > 0 ? N2 : 1],
-                                                    f32x16& acc2m, float* mid)
+                                                    float* mid)
 {
     constexpr int J0 = MM ? 32 : 0;                  // first output channel of the register (VALU) path
     float* wp = red + (xi * 64 + m) * WG_LDR + 4 * h;
@@ -233,7 +233,16 @@ __device__ __forceinline__ void wg_output_tile_head(const ConvArgs& a, const WgH
         }
     }
     if constexpr (MM) {
-        // second MFMA phase: wave xi owns pixels 32*xi .. +31 of the tile (two rows of 16); D[out j][pixel]
+        // second MFMA phase: wave xi owns pixels 32*xi .. +31 of the tile (two rows of 16); D[out j][pixel].  The 32x32
+        // accumulator lives across the block's channel tiles in a thread-private LDS slot (`park`, [4][256 threads] float4 behind
+        // `mid`): next to V (128) + the 3x3 accumulators (64) + two U sets (32) sixteen more live registers spill to scratch
+        float* pk = mid + WGH_MID + tid * 4;
+        f32x16 acc2m;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            const wg_v4 t4 = wg_lds4(pk + r4 * 4 * IG_THREADS);
+            acc2m[4 * r4] = t4.x; acc2m[4 * r4 + 1] = t4.y; acc2m[4 * r4 + 2] = t4.z; acc2m[4 * r4 + 3] = t4.w;
+        }
         __syncthreads();
         const float* mp = mid + (32 * xi + m) * WGH_LDM + 4 * h;
         wg_v4 mf[4];
@@ -246,6 +255,9 @@ __device__ __forceinline__ void wg_output_tile_head(const ConvArgs& a, const WgH
             acc2m = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[s4].z, mf[s4].z, acc2m, 0, 0, 0);
             acc2m = __builtin_amdgcn_mfma_f32_32x32x2f32(w2f[s4].w, mf[s4].w, acc2m, 0, 0, 0);
         }
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            *reinterpret_cast<wg_v4*>(pk + r4 * 4 * IG_THREADS) = (wg_v4){acc2m[4 * r4], acc2m[4 * r4 + 1], acc2m[4 * r4 + 2], acc2m[4 * r4 + 3]};
     }
 }
 
@@ -466,7 +478,7 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
 #define WGV_SLOTS ((WGV_F4 + IG_THREADS - 1) / IG_THREADS)  // 12
 #define WGV_CG (10 * WG_PWP * 4)                            // floats per 4-channel plane
 #define WGV_SMEM_FLOATS (2 * WG_RED)                        // two reduction buffers (73.7 KB) >= the 51.2 KB patch
-#define WGV_SMEM_FLOATS_MM (WG_RED + WGH_MID)               // MM: one reduction buffer + the mid tile (55.3 KB) >= the patch
+#define WGV_SMEM_FLOATS_MM (WG_RED + WGH_MID + 16 * IG_THREADS)   // MM: one reduction buffer + the mid tile + the parked 1x1 accumulators (71.7 KB)
 
 // N2: output channels of the head's 1x1 on the register path (0: none); MM = 1: second MFMA phase for outputs 0..31 of the 1x1
 // (then the register path handles outputs 32 .. 32 + N2 - 1).  <0, 0> = plain convolution.
@@ -574,9 +586,11 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int j = 0; j < (N2 > 0 ? N2 : 1); ++j) acc2[i][k][j] = 0.f;
-    f32x16 acc2m;
+    if constexpr (MM) {                                    // parked 1x1 accumulators: thread-private slots beyond the patch region
+        static_assert(WG_RED + WGH_MID >= WGV_CGS * WGV_CG, "park must not overlap the patch");
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc2m[r] = 0.f;
+        for (int r4 = 0; r4 < 4; ++r4) *reinterpret_cast<wg_v4*>(smem + WG_RED + WGH_MID + tid * 4 + r4 * 4 * IG_THREADS) = (wg_v4){0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll 1
     for (int nt = nt0; nt < nt1; ++nt) {
         f32x16 acc[4];
@@ -610,8 +624,8 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
         // MM: ONE reduction buffer + `mid`; the second barrier of the output stage (between the mid writes and the MFMA phase) is
         // what separates this tile's reads of the reduction buffer from the next tile's writes, and the first barrier of the
         // next tile separates this tile's mid reads from the next tile's mid writes.
-        if constexpr (MM) wg_output_tile_head<N2, 1>(a, hd, smem, acc, xi, h, m, tid, y0, x0, nt, acc2, acc2m, smem + WG_RED);
-        else if constexpr (N2 > 0) wg_output_tile_head<N2, 0>(a, hd, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, y0, x0, nt, acc2, acc2m, nullptr);
+        if constexpr (MM) wg_output_tile_head<N2, 1>(a, hd, smem, acc, xi, h, m, tid, y0, x0, nt, acc2, smem + WG_RED);
+        else if constexpr (N2 > 0) wg_output_tile_head<N2, 0>(a, hd, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, y0, x0, nt, acc2, nullptr);
         else wg_output_tile(a, smem + ((nt - nt0) & 1) * WG_RED, acc, xi, h, m, tid, b, y0, x0, nt, true);
     }
     if constexpr (MM) {
@@ -621,9 +635,13 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino_vs64_kernel(const 
         const int nmm = hd.n2 < 32 ? hd.n2 : 32;
         if (ox < a.W && oy < a.H) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int j = (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (j < nmm) hd.out2[((size_t)b * hd.n2 + j) * HW + (size_t)oy * a.W + ox] = cp_act(acc2m[r] + hd.b2[j], hd.act2);
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const wg_v4 t4 = wg_lds4(smem + WG_RED + WGH_MID + tid * 4 + r4 * 4 * IG_THREADS);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int j = e + 8 * r4 + 4 * h;
+                    if (j < nmm) hd.out2[((size_t)b * hd.n2 + j) * HW + (size_t)oy * a.W + ox] = cp_act(t4[e] + hd.b2[j], hd.act2);
+                }
             }
         }
     }

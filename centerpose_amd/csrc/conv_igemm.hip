@@ -230,6 +230,8 @@ struct cp_conv_desc {
     int nsub;     // 0 / 1: one conv; 4: fused sub-pixel deconvolution (see ConvArgs::nsub)
 };
 
+extern "C" int cp_sizeof_conv_desc(void) { return (int)sizeof(cp_conv_desc); }
+
 static int conv_args_from_desc(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale,
                                const float* shift, const float* res, float* out, ConvArgs& a)
 {
@@ -259,7 +261,7 @@ static int conv_args_from_desc(const cp_conv_desc* d, const float* const* src, c
     a.K = d->K; a.w = w; a.ldw = d->ldw; a.scale = scale; a.shift = shift;
     a.res = res; a.resLd = d->resLd; a.out = out; a.outLd = d->outLd; a.Cout = d->Cout;
     a.outNCHW = d->outNCHW; a.OH = d->OH; a.OW = d->OW; a.osy = d->osy; a.osx = d->osx; a.ooy = d->ooy; a.oox = d->oox;
-    a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1; a.nsub = d->nsub > 1 ? d->nsub : 1;
+    a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1; a.ksplit = 1; a.nsub = d->nsub > 1 ? d->nsub : 1;
     CP_CHECK_ARG(a.M > 0 && (long long)d->B * d->H * d->W < (1ll << 31), "conv2d: bad problem size");
     for (int i = 0; i < d->nsrc && !d->inNCHW; ++i)
         CP_CHECK_ARG((long long)d->B * d->H * d->W * d->srcLd[i] * 4 < (1ll << 32), "conv2d: source %d exceeds 32-bit byte offsets", i);
@@ -324,7 +326,7 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
 
 // Winograd F(2x2,3x3) path (conv3x3_wino.hip): same descriptor, `u` = cp_winograd_pack_f32 output.
 // d->tile: 0 = auto, 1 / 2 = 32 / 64 output channels per block.
-// KeypointHead branch (lib/models/heads/keypoint.py:14-37) with n2 <= 2 outputs as ONE launch: d / src / u / scale / shift describe the
+// KeypointHead branch (lib/models/heads/keypoint.py:14-37) with n2 <= 34 outputs as ONE launch: d / src / u / scale / shift describe the
 // 3x3 conv (C = 64 -> Cmid, bias in `shift`, act = ReLU) exactly as for cp_conv3x3_winograd_f32; w2 [n2][ld2] / b2 [n2] are the
 // 1x1 conv; out2 is the reference's NCHW output [B, n2, H, W]; act2 = CP_ACT_SIGMOID for hm (multi_pose.py:35-37).
 extern "C" int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
@@ -335,7 +337,7 @@ extern "C" int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const
     CP_CHECK_ARG(d && d->nsrc == 1 && !d->inNCHW && w2 && b2 && out2, "head3x3_1x1: one NHWC source and the 1x1 operands expected");
     if (int rc = conv_args_from_desc(d, srcs, u, scale, shift, nullptr, out2, a)) return rc;
     const int rc = cp_launch_head3x3_1x1(a, w2, b2, out2, n2, ld2, act2, (hipStream_t)stream);
-    CP_CHECK_ARG(rc >= 0, "head3x3_1x1: shape not eligible (C = 64, Cmid %% 32 == 0, ReLU, n2 <= 2, 16-byte aligned operands)");
+    CP_CHECK_ARG(rc >= 0, "head3x3_1x1: shape not eligible (C = 64, Cmid %% 32 == 0, ReLU, n2 <= 34, 16-byte aligned operands)");
     if (rc) return rc;
     CP_CHECK_LAUNCH("conv3x3_wino_vs64_kernel");
     return 0;

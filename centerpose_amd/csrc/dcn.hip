@@ -40,12 +40,17 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int NT = a.ldw / BN;
-    const int tile = ig_xcd_remap(blockIdx.x, gridDim.x);
+    int tile = ig_xcd_remap(blockIdx.x, gridDim.x);
+    // split-K over the taps (small-M layers: 512 -> 256 @16x16 is 256 blocks of 288 k-steps on 256 CUs): consecutive blocks are
+    // the splits of one tile, so they gather from the same neighbourhood
+    const int S = a.ksplit, sp = tile % S;
+    tile /= S;
     const int nt = tile % NT, mt = tile / NT;
     const int m0 = mt * BM, n0 = nt * BN;
     const int wm0 = (wid / WAVES_N) * T::WM, wn0 = (wid % WAVES_N) * T::WN;
     const int HoWo = a.Ho * a.Wo;
     const int ntap = a.kh * a.kw;
+    const int tap0 = sp * ntap / S, tap1 = (sp + 1) * ntap / S;       // this block's taps
     const int C = a.srcC[0], ld = a.srcLd[0];
     const float* __restrict__ x = a.src[0];
 
@@ -62,7 +67,7 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
         const float* omp = a.om + (size_t)(live ? m : 0) * a.omLd;
         const int by = oy * a.sy - a.py, bx = ox * a.sx - a.px, bpix = b * a.H * a.W;
         const float fH = (float)a.H, fW = (float)a.W;
-        for (int t = tid / BM; t < ntap; t += IG_THREADS / BM) {
+        for (int t = tap0 + tid / BM; t < tap1; t += IG_THREADS / BM) {
             const int ky = t / a.kw, kx = t - ky * a.kw;                   // wave-uniform
             float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
             int code = 0;
@@ -104,11 +109,11 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
 #pragma unroll
             for (int r = 0; r < IgAcc<MF>::N; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.K / IG_BK;
+    const int ks0 = tap0 * (C / IG_BK), nk = tap1 * (C / IG_BK);       // k-steps [ks0, nk)
     const int q = tid % QL;
     float4 br[T::B_SLOTS];
     float4 c00[ASL], c01[ASL], c10[ASL], c11[ASL], wq[ASL];
-    int tap = 0, cl = 0;
+    int tap = tap0, cl = 0;
     __syncthreads();
 
     // Corner byte offsets and blend weights are per (tap, pixel): computed at the first k-step of a tap and reused by its
@@ -158,12 +163,12 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     };
 
     load_a(); advance();
-    ig_load_b<T>(a, 0, n0, tid, br);
+    ig_load_b<T>(a, ks0 * IG_BK, n0, tid, br);
     store_a(As0);
     ig_store_b<T>(Bs0, tid, br);
     __syncthreads();
     int cur = 0;
-    for (int ks = 0; ks < nk; ++ks) {
+    for (int ks = ks0; ks < nk; ++ks) {
         const bool more = ks + 1 < nk;
         // the next step's gathers are issued from inside the MFMA block (half-way through the k-step)
         ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
@@ -179,7 +184,12 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
         __syncthreads();
         cur ^= 1;
     }
-    ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc);
+    if (S > 1) {
+        // raw partial sums of this split (the launcher passes scale = 1, shift = 0, no activation, NHWC with outLd = ldw)
+        ConvArgs e = a;
+        e.out = a.out + (size_t)sp * a.M * a.outLd;
+        ig_epilogue<T, BM, BN, MF>(e, smem, m0, n0, wm0, wn0, lane, tid, acc);
+    } else ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc);
 }
 
 
@@ -196,7 +206,7 @@ static int launch_dcn(const ConvArgs& a, hipStream_t s)
     static CpLdsGuard guard;
     if (smem > 64 * 1024 && guard.need(smem))
         (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-    const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN);
+    const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN) * a.ksplit;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
     cp_note_kernel("dcn_igemm_kernel<%d, %d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N, MF);
     return 0;
@@ -210,7 +220,11 @@ struct cp_dcn_desc {
     int omLd, omSigmoid;       // om[B,Ho,Wo,omLd]: 2k = dy, 2k+1 = dx, 2*kh*kw + k = mask (logit if omSigmoid)
     int outLd, outNCHW, act;
     int tile;
+    int ksplit;                // 0 / 1: whole K in one block.  S > 1: split-K over the taps -- `out` is a workspace [S][M][outLd] of raw
+                               // partial sums (pass scale = 1, shift = 0, act = none, NHWC, outLd = ldw); cp_splitk_reduce_f32 finishes
 };
+
+extern "C" int cp_sizeof_dcn_desc(void) { return (int)sizeof(cp_dcn_desc); }
 
 extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* om, const float* w, const float* scale,
                              const float* shift, float* out, void* stream)
@@ -233,11 +247,15 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
     a.OH = d->Ho; a.OW = d->Wo; a.osy = a.osx = 1; a.ooy = a.oox = 0; a.act = d->act;
     a.om = om; a.omLd = d->omLd; a.omMaskOff = 2 * d->kh * d->kw; a.omSigmoid = d->omSigmoid;
     a.dily = d->dily; a.dilx = d->dilx; a.nsub = 1;
+    a.ksplit = d->ksplit > 1 ? d->ksplit : 1;
+    CP_CHECK_ARG(a.ksplit <= d->kh * d->kw, "dcn_v2: ksplit=%d exceeds the %d taps", a.ksplit, d->kh * d->kw);
+    CP_CHECK_ARG(a.ksplit == 1 || (!d->outNCHW && d->act == CP_ACT_NONE && d->outLd == d->ldw && d->Cout == d->ldw),
+                 "dcn_v2: split-K writes raw NHWC partial sums (outLd == Cout == ldw, no activation)");
     hipStream_t s = (hipStream_t)stream;
     int tile = d->tile;
     if (tile == 0) {
         static const int force = getenv("CP_DCN_TILE") ? atoi(getenv("CP_DCN_TILE")) : 0;      // A/B switch for profiling
-        if (force) tile = force;
+        if (force && a.ksplit == 1) tile = force;
     }
     if (tile == 0) {
         if (d->ldw % 64 != 0) tile = (d->ldw % 32 == 0) ? 128032 : 0;
@@ -251,6 +269,14 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
                                 // interleave gather and MFMA phases better; the kernel is L1-gather-bound, not tile-reuse-bound)
     }
     int rc = 0;
+    if (tile == 9000064) {                       // wave-private-A structure (dcn_wp.hip)
+        CP_CHECK_ARG(a.ksplit == 1, "dcn_v2: split-K is implemented by dcn_igemm_kernel only");
+        rc = cp_launch_dcn_wp(a, s, 64);
+        CP_CHECK_ARG(rc >= 0, "dcn_v2: the wave-private-A kernel needs C %% 64 == 0 and ldw %% 64 == 0 (C=%d ldw=%d)", d->C, d->ldw);
+        if (rc) return rc;
+        CP_CHECK_LAUNCH("dcn_wp_kernel");
+        return 0;
+    }
     switch (tile) {
         case 128032: rc = launch_dcn<128, 32, 4, 1, 32>(a, s); break;
         case 128064: rc = launch_dcn<128, 64, 2, 2, 32>(a, s); break;

@@ -124,6 +124,40 @@ extern "C" int cp_dw_deconv_add_nhwc_f32(const float* in, int inLd, const float*
     return 0;
 }
 
+// ---- second half of a split-K DCNv2 launch (dcn.hip, cp_dcn_desc.ksplit): sum the S raw partial-sum slices in a FIXED order
+// (deterministic, unlike float atomics), then scale / shift (folded BN + bias) + activation, NHWC store of the first Cout channels
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int S, long long slice, int ldw4, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, int act, float* __restrict__ out, int outLd, int Cout, long long total4)
+{
+    const long long i = (long long)blockIdx.x * EW_THREADS + threadIdx.x;          // float4 index into one slice [M][ldw]
+    if (i >= total4) return;
+    const long long m = i / ldw4;
+    const int n = (int)(i - m * ldw4) * 4;
+    if (n >= Cout) return;
+    float4 acc = *reinterpret_cast<const float4*>(ws + i * 4);
+    for (int s = 1; s < S; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(ws + (size_t)s * slice + i * 4);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    const float4 sc = *reinterpret_cast<const float4*>(scale + n), sh = *reinterpret_cast<const float4*>(shift + n);
+    acc.x = cp_act(acc.x * sc.x + sh.x, act); acc.y = cp_act(acc.y * sc.y + sh.y, act);
+    acc.z = cp_act(acc.z * sc.z + sh.z, act); acc.w = cp_act(acc.w * sc.w + sh.w, act);
+    *reinterpret_cast<float4*>(out + (size_t)m * outLd + n) = acc;
+}
+
+extern "C" int cp_splitk_reduce_f32(const float* ws, int splits, int M, int ldw, const float* scale, const float* shift, int act, float* out,
+                                    int outLd, int Cout, void* stream)
+{
+    CP_CHECK_ARG(ws && scale && shift && out && splits >= 1 && M > 0, "splitk_reduce: bad arguments");
+    CP_CHECK_ARG(ldw % 4 == 0 && Cout % 4 == 0 && outLd % 4 == 0 && Cout <= ldw && Cout <= outLd, "splitk_reduce: ldw, Cout, outLd must be multiples of 4 (ldw=%d Cout=%d outLd=%d)", ldw, Cout, outLd);
+    const long long total4 = (long long)M * (ldw / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total4 + EW_THREADS - 1) / EW_THREADS)), dim3(EW_THREADS), 0, (hipStream_t)stream,
+                       ws, splits, (long long)M * ldw, ldw / 4, scale, shift, act, out, outLd, Cout, total4);
+    cp_note_kernel("splitk_reduce_kernel");
+    CP_CHECK_LAUNCH("splitk_reduce_kernel");
+    return 0;
+}
+
 // out = act( sum_i nearest_up(src_i, 2^sh_i) ), all NHWC with C channels; out is [B,H,W,C]
 struct SumUpArgs { const float* src[4]; int ld[4]; int sh[4]; int n; };
 __global__ void sum_up_kernel(SumUpArgs a, float* __restrict__ out, int outLd, EwRow r, int H, int W, int relu)

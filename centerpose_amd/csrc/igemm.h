@@ -56,6 +56,8 @@ struct ConvArgs {
     int omMaskOff;            // first mask channel (2*kh*kw)
     int omSigmoid;            // 1: mask channel holds logits (apply sigmoid), 0: mask given directly
     int dily, dilx;           // dilation (DCNv2 drop-in only; plain convs are dilation 1)
+    int ksplit;               // DCNv2 only: > 1 = split-K over the taps: block (tile, split s) accumulates taps [s*T/S, (s+1)*T/S) and
+                              // stores the RAW partial sums to out + s*M*outLd (cp_splitk_reduce_f32 sums them in a fixed order)
     int nsub;                 // 1, or 4: the four sub-pixel 2x2 convs of a k4/s2/p1 ConvTranspose2d in ONE launch (generic kernel only):
                               // sub g = py*2+px uses weights w + g*ldw*K, pad (py0 - py, px0 - px) and output phase (ooy + py, oox + px)
 };
@@ -64,6 +66,8 @@ struct ConvArgs {
 int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s, int variant = 0);
 // conv3x3_wino.hip (a.w = Winograd-domain weights): same convention
 int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant = 0);
+// dcn_wp.hip: DCNv2 with wave-private A tiles, bn output channels per block; -1 = shape not eligible
+int cp_launch_dcn_wp(const ConvArgs& a, hipStream_t s, int bn);
 // conv3x3_wino.hip: [3x3 + bias + ReLU] + 1x1 (n2 <= 2 outputs, NCHW) of a head branch in one launch; -1 = shape not eligible
 int cp_launch_head3x3_1x1(const ConvArgs& a, const float* w2, const float* b2, float* out2, int n2, int ld2, int act2, hipStream_t s);
 

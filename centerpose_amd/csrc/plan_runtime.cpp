@@ -29,6 +29,9 @@ int cp_scale_add_nhwc_f32(const float*, int, const float*, int, const float*, in
 int cp_shuffle_concat_nhwc_f32(const float*, int, const float*, int, float*, int, long long, int, int, void*);
 int cp_multi_pose_decode_f32(const float*, const float*, const float*, const float*, const float*, const float*, int, int, int, int,
                              int, int, float*, float*, int*, void*);
+int cp_splitk_reduce_f32(const float*, int, int, int, const float*, const float*, int, float*, int, int, void*);
+int cp_sizeof_conv_desc(void);
+int cp_sizeof_dcn_desc(void);
 int cp_decode_topk_f32(const float*, const float*, int, int, int, int, int, int, float*, int*, void*);
 int cp_decode_assign_f32(const float*, const float*, const float*, const float*, const float*, const int*, int, int, int, int, int, float*,
                          void*);
@@ -37,7 +40,7 @@ int cp_decode_assign_f32(const float*, const float*, const float*, const float*,
 namespace {
 
 enum { FN_CONV = 1, FN_WINO = 2, FN_DCN = 3, FN_STEM7 = 4, FN_POOL = 5, FN_UPADD = 6, FN_SUMUP = 7, FN_DWCONV = 8, FN_AVGPOOL = 9,
-       FN_SCALEADD = 10, FN_SHUFFLE = 11, FN_HEAD = 12, FN_TOPK = 13, FN_ASSIGN = 14 };   // ops.FN_IDS
+       FN_SCALEADD = 10, FN_SHUFFLE = 11, FN_HEAD = 12, FN_TOPK = 13, FN_ASSIGN = 14, FN_SPLITK = 15 };   // ops.FN_IDS
 enum { REF_NULL = 0, REF_BUF = 1, REF_CONST = 2 };
 
 struct Op {
@@ -119,6 +122,8 @@ int run_op(const Op& o, hipStream_t s)
             return cp_scale_add_nhwc_f32(P[0], I[0], P[1], I[1], P[2], I[2], P[3], I[3], I[4], I[5], I[6], I[7], s);
         case FN_SHUFFLE:
             return cp_shuffle_concat_nhwc_f32(P[0], I[0], P[1], I[1], P[2], I[2], (long long)I[3], I[4], I[5], s);
+        case FN_SPLITK:
+            return cp_splitk_reduce_f32(P[0], I[0], I[1], I[2], P[1], P[2], I[3], P[3], I[4], I[5], s);
         case FN_TOPK:
             return cp_decode_topk_f32(P[0], P[1], I[0], I[1], I[2], I[3], I[4], I[5], P[2], reinterpret_cast<int*>(P[3]), s);
         case FN_ASSIGN:
@@ -132,17 +137,19 @@ int run_op(const Op& o, hipStream_t s)
 bool arity_ok(const Op& o)
 {
     switch (o.fn) {
-        case FN_CONV: return o.ptrs.size() == 9 && o.desc.size() >= 4;
-        case FN_WINO: case FN_DCN: return o.ptrs.size() == 6 && o.desc.size() >= 4;
+        case FN_CONV: return o.ptrs.size() == 9 && (int)o.desc.size() == cp_sizeof_conv_desc();
+        case FN_WINO: return o.ptrs.size() == 6 && (int)o.desc.size() == cp_sizeof_conv_desc();
+        case FN_DCN: return o.ptrs.size() == 6 && (int)o.desc.size() == cp_sizeof_dcn_desc();
         case FN_STEM7: return o.ptrs.size() == 5 && o.ints.size() == 7;
         case FN_POOL: return o.ptrs.size() == 2 && o.ints.size() == 9;
         case FN_UPADD: return o.ptrs.size() == 4 && o.ints.size() == 8;
         case FN_SUMUP: return o.ptrs.size() == 5 && o.ints.size() == 15;
-        case FN_HEAD: return o.ptrs.size() == 7 && o.ints.size() == 3 && o.desc.size() >= 4;
+        case FN_HEAD: return o.ptrs.size() == 7 && o.ints.size() == 3 && (int)o.desc.size() == cp_sizeof_conv_desc();
         case FN_DWCONV: return o.ptrs.size() == 5 && o.ints.size() == 10;
         case FN_AVGPOOL: return o.ptrs.size() == 2 && o.ints.size() == 5;
         case FN_SCALEADD: return o.ptrs.size() == 4 && o.ints.size() == 8;
         case FN_SHUFFLE: return o.ptrs.size() == 3 && o.ints.size() == 6;
+        case FN_SPLITK: return o.ptrs.size() == 4 && o.ints.size() == 6;
         case FN_TOPK: return o.ptrs.size() == 4 && o.ints.size() == 6;
         case FN_ASSIGN: return o.ptrs.size() == 7 && o.ints.size() == 5;
     }

@@ -72,7 +72,7 @@ at::Tensor dcn_v2_forward(const at::Tensor& input, const at::Tensor& weight, con
     cp_dcn_desc d = {};
     d.B = B; d.H = H; d.W = W; d.C = Cp; d.srcLd = Cp; d.Ho = Ho; d.Wo = Wo;
     d.kh = kernel_h; d.kw = kernel_w; d.sy = stride_h; d.sx = stride_w; d.py = pad_h; d.px = pad_w; d.dily = dilation_h; d.dilx = dilation_w;
-    d.K = kk * Cp; d.ldw = ldw; d.Cout = Co; d.omLd = omld; d.omSigmoid = 0; d.outLd = 0; d.outNCHW = 1; d.act = CP_ACT_NONE; d.tile = 0;
+    d.K = kk * Cp; d.ldw = ldw; d.Cout = Co; d.omLd = omld; d.omSigmoid = 0; d.outLd = 0; d.outNCHW = 1; d.act = CP_ACT_NONE; d.tile = 0; d.ksplit = 0;
     CP_CALL(cp_dcn_v2_f32(&d, x.data_ptr<float>(), om.data_ptr<float>(), wp.data_ptr<float>(), scale.data_ptr<float>(),
                           shift.data_ptr<float>(), out.data_ptr<float>(), cur_stream(input)), "cp_dcn_v2_f32");
     return out;

@@ -76,7 +76,8 @@ class PlanBuilder(nets.Graph):
         self.launches = []      # (kind, name, algorithmic flops_per_batch, ops.Launch); kind 'wino' = 3x3 conv on the Winograd kernel
         # CP_WINOGRAD=0 keeps every 3x3 on the direct (patch) kernel: A/B switch for tests and profiling
         self.winograd = os.environ.get("CP_WINOGRAD", "1") != "0"
-        self.fuse_heads = os.environ.get("CP_FUSE_HEADS", "1") != "0"      # 3x3 + 1x1 of the <= 2-output head branches in one launch
+        self.dcn_splitk = os.environ.get("CP_DCN_SPLITK", "1") != "0"      # split-K for the DCNv2 layers that cannot fill the CUs
+        self.fuse_heads = os.environ.get("CP_FUSE_HEADS", "1") != "0"      # 3x3 + 1x1 of a head branch in one launch
         self._pool_cache = {}
         self.outputs = None
 
@@ -190,7 +191,20 @@ class PlanBuilder(nets.Graph):
         uom = self.wino(wom, x.t.shape[3], 32)
         self.add("wino" if uom is not None else "conv", conv + ".conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9,
                  ops.conv2d_launch([x.t], wom, som, hom, om.t, kh=3, kw=3, stride=1, pad=1, cout=32, wino=uom))
-        self.add("dcn", conv, 2 * x.H * x.W * co * x.C * 9,
+        flops = 2 * x.H * x.W * co * x.C * 9
+        S = ops.dcn_ksplit(self.B * x.H * x.W, wp.shape[0]) if self.dcn_splitk else 1
+        if S > 1:
+            # small-M layer (512 -> 256 @16x16 at B = 16 is 256 blocks of 288 k-steps on 256 CUs): split-K over the taps into a
+            # workspace of raw partial sums, then a fixed-order reduction + BN + ReLU (deterministic; two launches)
+            ldw = wp.shape[0]
+            ws = self.pool.take(S * self.B * x.H * x.W * ldw)
+            wst = ws[: S * self.B * x.H * x.W * ldw].view(S, self.B * x.H * x.W, ldw)
+            ones, zeros = torch.ones(ldw, device=self.dev), torch.zeros(ldw, device=self.dev)
+            self.add("dcn", conv, flops, ops.dcn_v2_launch(x.t, om.t, wp, ones, zeros, wst, cout=ldw, om_sigmoid=True, ksplit=S))
+            self.add("sum", conv + ".splitk", 0, ops.splitk_reduce_launch(wst, sc, sh, out.t, cout=out.t.shape[3], act=ops.ACT_RELU))
+            self.pool.give(ws)
+            return out
+        self.add("dcn", conv, flops,
                  ops.dcn_v2_launch(x.t, om.t, wp, sc, sh, out.t, cout=out.t.shape[3], om_sigmoid=True, act=ops.ACT_RELU))
         return out
 
@@ -288,8 +302,8 @@ class PlanBuilder(nets.Graph):
                 sc3h, sh3h = ops.fold_bn(hc, None, self.w("%s.%s.0.bias" % (p, h)), self.dev)
                 u3h = self.wino(wp3h, feat.t.shape[3], hc)
                 if u3h is not None and self.fuse_heads and ops.head3x3_1x1_eligible(ft, hc, n):
-                    # branches with <= 2 outputs (hm, wh, reg, hp_offset): the 1x1 rides in the Winograd kernel's epilogue,
-                    # the [B,H,W,hc] intermediate (268 MB at B = 16) is neither written nor read back
+                    # the 1x1 rides in the Winograd kernel (<= 2 outputs: epilogue registers; hps / hm_hp: a second MFMA phase
+                    # over the LDS-resident tile): the [B,H,W,hc] intermediate (268 MB at B = 16) is neither written nor read back
                     w2 = self.w("%s.%s.2.weight" % (p, h)).reshape(n, hc).contiguous()
                     self.add("wino", "%s.%s.0+2" % (p, h), 2 * H * W * (hc * feat.C * 9 + n * hc),
                              ops.head3x3_1x1_launch(ft, u3h, sc3h, sh3h, w2, self.w("%s.%s.2.bias" % (p, h)), o, hc=hc, act2=act))

@@ -24,7 +24,7 @@ class ConvDesc(ctypes.Structure):
 class DcnDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("B", "H", "W", "C", "srcLd", "Ho", "Wo", "kh", "kw", "sy", "sx", "py", "px",
                                             "dily", "dilx", "K", "ldw", "Cout", "omLd", "omSigmoid", "outLd",
-                                            "outNCHW", "act", "tile")]
+                                            "outNCHW", "act", "tile", "ksplit")]
 
 
 def round_up(x, m):
@@ -99,6 +99,8 @@ def marshal(fn, desc, ptrs, ints):
         return [ptrs[0], ints[0], ptrs[1], ints[1], ptrs[2], ints[2], ptrs[3]] + ints[3:]
     if fn == "cp_shuffle_concat_nhwc_f32":        # ptrs: x1, x2, out; ints: ld1, ld2, outLd, npix, h, hp
         return [ptrs[0], ints[0], ptrs[1], ints[1], ptrs[2], ints[2], ctypes.c_longlong(ints[3]), ints[4], ints[5]]
+    if fn == "cp_splitk_reduce_f32":              # ptrs: ws, scale, shift, out; ints: splits, M, ldw, act, outLd, Cout
+        return [ptrs[0], ints[0], ints[1], ints[2], ptrs[1], ptrs[2], ints[3], ptrs[3], ints[4], ints[5]]
     if fn == "cp_decode_topk_f32":                # ptrs: heat, hm_hp, ws_scores, ws_inds; ints: B, cat, J, H, W, K
         return ptrs[:2] + ints + ptrs[2:]
     if fn == "cp_decode_assign_f32":              # ptrs: wh, kps, reg, hp_offset, ws_scores, ws_inds, dets; ints: B, J, H, W, K
@@ -109,7 +111,7 @@ def marshal(fn, desc, ptrs, ints):
 FN_IDS = {"cp_conv2d_f32": 1, "cp_conv3x3_winograd_f32": 2, "cp_dcn_v2_f32": 3, "cp_stem7x7_f32": 4,
           "cp_maxpool2d_nhwc_f32": 5, "cp_dw_deconv_add_nhwc_f32": 6, "cp_sum_up_nhwc_f32": 7, "cp_dwconv2d_nhwc_f32": 8,
           "cp_global_avgpool_nhwc_f32": 9, "cp_scale_add_nhwc_f32": 10, "cp_shuffle_concat_nhwc_f32": 11, "cp_head3x3_1x1_f32": 12,
-          "cp_decode_topk_f32": 13, "cp_decode_assign_f32": 14}
+          "cp_decode_topk_f32": 13, "cp_decode_assign_f32": 14, "cp_splitk_reduce_f32": 15}
 
 
 def pad_rows(t, ldw):
@@ -229,14 +231,15 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
 
 
 def head3x3_1x1_eligible(x, hc, n2):
-    """the fused head launch: 64 physical input channels, mid channels a multiple of 32, at most two outputs, and enough
-    spatial tiles to fill the chip (the V-stationary Winograd kernel's own condition)."""
+    """the fused head launch: 64 physical input channels, mid channels a multiple of 32, at most 34 outputs (<= 2: epilogue
+    registers; 3..34: second MFMA phase for the first 32 + registers for the rest), and enough spatial tiles to fill the chip
+    (the V-stationary Winograd kernel's own condition)."""
     B, H, W, C = x.shape
-    return C == 64 and hc % 32 == 0 and hc >= 128 and 1 <= n2 <= 2 and B * ((H + 7) // 8) * ((W + 15) // 16) >= 512
+    return C == 64 and hc % 32 == 0 and hc >= 128 and 1 <= n2 <= 34 and B * ((H + 7) // 8) * ((W + 15) // 16) >= 512
 
 
 def head3x3_1x1_launch(x, u, scale, shift, w2, b2, out2, *, hc, act2=ACT_NONE):
-    """One KeypointHead branch (3x3 conv + bias + ReLU -> 1x1 conv + bias [+ sigmoid]) with n2 <= 2 outputs in one launch.
+    """One KeypointHead branch (3x3 conv + bias + ReLU -> 1x1 conv + bias [+ sigmoid]) with n2 <= 34 outputs in one launch.
     x NHWC [B,H,W,64]; u = pack_wino_weight(3x3 weights); scale / shift [>= hc]; w2 [n2, ld2] contiguous; out2 NCHW [B,n2,H,W]."""
     B, H, W, C = x.shape
     n2, ld2 = w2.shape
@@ -278,8 +281,10 @@ def dcn_v2(x, om, wp, scale, shift, out, **kw):
 
 
 def dcn_v2_launch(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, pad=1, dil=1, om_sigmoid=True,
-                  act=ACT_NONE, out_nchw=False, tile=0):
-    """Fused DCNv2: x NHWC [B,H,W,C]; om NHWC [B,Ho,Wo,>=3*kh*kw] (dy,dx pairs then mask)."""
+                  act=ACT_NONE, out_nchw=False, tile=0, ksplit=0):
+    """Fused DCNv2: x NHWC [B,H,W,C]; om NHWC [B,Ho,Wo,>=3*kh*kw] (dy,dx pairs then mask).
+    ksplit = S > 1: split-K over the taps; `out` is then the workspace [S, B*Ho*Wo, ldw] of raw partial sums (scale = ones,
+    shift = zeros, act none, cout = ldw) and `splitk_reduce_launch` finishes the layer."""
     B, H, W, C = x.shape
     d = DcnDesc()
     Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
@@ -290,9 +295,31 @@ def dcn_v2_launch(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, p
     d.K, d.ldw, d.Cout = wp.shape[1], wp.shape[0], cout
     d.omLd, d.omSigmoid = _ld(om), 1 if om_sigmoid else 0
     d.outNCHW = 1 if out_nchw else 0
-    d.outLd = 0 if out_nchw else _ld(out)
-    d.act, d.tile = act, tile
+    d.act, d.tile, d.ksplit = act, tile, ksplit
+    if ksplit > 1:
+        assert tuple(out.shape) == (ksplit, B * Ho * Wo, wp.shape[0]) and out.is_contiguous() and cout == wp.shape[0] and act == ACT_NONE
+        d.outLd = wp.shape[0]
+    else:
+        d.outLd = 0 if out_nchw else _ld(out)
     return Launch("cp_dcn_v2_f32", d, [x, om, wp, scale, shift, out])
+
+
+def dcn_ksplit(M, ldw):
+    """Split-K factor for a DCNv2 launch with M output pixels and ldw (padded) output channels: 3 (three taps per block) when the
+    64 x 64 tiling gives fewer than 2 blocks per CU on 256 CUs, else 1.  Measured on MI355X, B = 16: 512 -> 256 @16x16 runs at
+    50 TF unsplit (256 blocks x 288 k-steps), 256 -> 64 @32x32 at 48 TF."""
+    if ldw % 64 != 0:
+        return 1
+    blocks = -(-M // 64) * (ldw // 64)
+    return 3 if blocks < 512 else 1
+
+
+def splitk_reduce_launch(ws, scale, shift, out, *, cout, act=ACT_NONE):
+    """out[b,y,x,:cout] = act(sum_s ws[s] * scale + shift): the fixed-order reduction of a split-K DCNv2 launch.
+    ws [S, M, ldw] contiguous; out NHWC with B*H*W == M."""
+    S, M, ldw = ws.shape
+    assert ws.is_contiguous() and out.shape[0] * out.shape[1] * out.shape[2] == M and scale.numel() >= ldw and shift.numel() >= ldw
+    return Launch("cp_splitk_reduce_f32", None, [ws, scale, shift, out], [S, M, ldw, act, _ld(out), cout])
 
 
 def maxpool2d_launch(x, out, k, s, p):

@@ -74,8 +74,9 @@ int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, const float
                             const float* res, float* out, void* stream);
 
 /* One KeypointHead branch (lib/models/heads/keypoint.py:14-37: conv3x3(C -> head_conv, bias) -> ReLU -> conv1x1(head_conv -> n, bias))
- * with n <= 2 outputs -- hm, wh, reg, hp_offset -- as ONE launch: the 1x1 is applied to every channel tile of the Winograd kernel
- * while it is on the CU, the [B,H,W,head_conv] intermediate is never written.  d / src / u / scale / shift: the 3x3 conv as for
+ * with n <= 34 outputs -- all six branches of the reference head -- as ONE launch: the 1x1 is applied to every channel tile of the
+ * Winograd kernel while it is on the CU (n <= 2: in the epilogue registers; more: a second MFMA phase over the LDS-resident tile),
+ * the [B,H,W,head_conv] intermediate is never written.  d / src / u / scale / shift: the 3x3 conv as for
  * cp_conv3x3_winograd_f32 (C = 64, act = CP_ACT_RELU); w2: [n2][ld2] (ld2 >= head_conv, % 4 == 0), b2: [n2]; out2: NCHW
  * [B,n2,H,W]; act2: CP_ACT_SIGMOID for hm (lib/detectors/multi_pose.py:35-37), else CP_ACT_NONE.  Returns 1 for other shapes. */
 int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
@@ -95,9 +96,20 @@ typedef struct cp_dcn_desc {
     int omLd, omSigmoid;
     int outLd, outNCHW, act;
     int tile;
+    int ksplit;     /* 0 / 1: none.  S > 1: split-K over the taps for small-M layers: `out` is a workspace [S][B*Ho*Wo][ldw] that receives
+                     * the raw partial sums (scale = ones, shift = zeros, act = CP_ACT_NONE, NHWC, outLd = Cout = ldw);
+                     * cp_splitk_reduce_f32 sums the S slices in a fixed order (deterministic) and applies scale / shift / act */
 } cp_dcn_desc;
 int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* om, const float* w, const float* scale,
                   const float* shift, float* out, void* stream);
+/* sizeof the two descriptor structs as THIS library was compiled: an FFI binder (ctypes, cgo, JNI) asserts its own layout against
+ * them, and the plan runtime rejects plan files whose descriptor blobs have another size */
+int cp_sizeof_conv_desc(void);
+int cp_sizeof_dcn_desc(void);
+
+/* second half of a split-K DCNv2 launch: out[m][n] = act((sum_s ws[s][m][n]) * scale[n] + shift[n]), n < Cout; NHWC out */
+int cp_splitk_reduce_f32(const float* ws, int splits, int M, int ldw, const float* scale, const float* shift, int act, float* out,
+                         int outLd, int Cout, void* stream);
 
 /* ---- 7x7 / pad 3 stem on the NCHW 3-channel network input ----------------------------------------
  * Replaces base_layer Conv2d(3,16,k7,s1,p3)+BN+ReLU (pose_dla_dcn.py:228-232) and conv1 Conv2d(3,64,k7,s2,p3)

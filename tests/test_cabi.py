@@ -30,8 +30,22 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_arch(lib):
-    assert lib.cp_abi_version() == 2
+    assert lib.cp_abi_version() == 3
     assert lib.cp_target_arch() == b"gfx950"
+
+
+def test_descriptor_layouts_match_the_library(lib):
+    """The ctypes mirrors of cp_conv_desc / cp_dcn_desc (centerpose_amd/ops.py) have the size the library was compiled with, and
+    the header declares the fields in the binder's order (an FFI binder's first check)."""
+    import ctypes
+    from centerpose_amd import ops
+    assert ctypes.sizeof(ops.ConvDesc) == lib.cp_sizeof_conv_desc()
+    assert ctypes.sizeof(ops.DcnDesc) == lib.cp_sizeof_dcn_desc()
+    src = open(os.path.join(ROOT, "include", "centerpose_hip.h")).read()
+    body = re.search(r"typedef struct cp_dcn_desc \{(.*?)\} cp_dcn_desc;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = [f.strip() for decl in re.findall(r"int ([^;]+);", body) for f in decl.split(",")]
+    assert fields == [n for n, _ in ops.DcnDesc._fields_]
 
 
 def test_no_cpu_fallback():

@@ -248,13 +248,44 @@ def _dcn_case(seed, B, C, Co, H, W, big_offsets):
     return x, w, b, off, m
 
 
+def test_dcn_v2_split_k_vs_scalar_oracle():
+    """cp_dcn_desc.ksplit: split-K over the taps into raw partial sums + cp_splitk_reduce_f32 (fixed-order sum, bias, ReLU) ==
+    the scalar oracle; S = 3 and the extreme S = 9 (one tap per block), ragged M, 64- and 128-wide N tiles; twice -> same bits."""
+    from centerpose_amd import ops
+    from oracle import dcn as odcn
+    for (C, Co, H, W, S, tile) in [(64, 64, 9, 7, 3, 0), (32, 128, 6, 10, 9, 64128), (128, 256, 8, 8, 3, 64064), (48, 64, 5, 9, 2, 0)]:
+        x, w, b, off, m = _dcn_case(C + S, 2, C, Co, H, W, True)
+        ref = np.maximum(odcn.dcn_v2_forward_c(x, w, b, off, m), 0.0)
+        om = torch.zeros(2, H, W, 32)
+        om[..., :18] = torch.from_numpy(off).permute(0, 2, 3, 1)
+        om[..., 18:27] = torch.from_numpy(m).permute(0, 2, 3, 1)
+        wp = ops.pack_conv_weight(torch.from_numpy(w).cuda())
+        ldw = wp.shape[0]
+        sc, sh = ops.fold_bn(Co, None, torch.from_numpy(b).cuda())
+        ws = torch.full((S, 2 * H * W, ldw), float("nan"), device="cuda")
+        out = torch.full((2, H, W, Co + 4), float("nan"), device="cuda")
+        xs, oms = _nhwc(torch.from_numpy(x)), om.cuda()
+        la = ops.dcn_v2_launch(xs, oms, wp, torch.ones(ldw, device="cuda"), torch.zeros(ldw, device="cuda"), ws, cout=ldw,
+                               om_sigmoid=False, tile=tile, ksplit=S)
+        lb = ops.splitk_reduce_launch(ws, sc, sh, out[..., :Co], cout=Co, act=ops.ACT_RELU)
+        la.run(); lb.run()
+        first = out.clone()
+        la.run(); lb.run()
+        assert torch.equal(first[..., :Co], out[..., :Co]) and torch.isnan(out[..., Co:]).all()
+        _close(out[..., :Co].permute(0, 3, 1, 2), torch.from_numpy(ref), 1e-4)
+
+
 @pytest.mark.parametrize("C,Co,H,W,big,tile", [(16, 64, 12, 10, True, 0), (64, 64, 16, 16, False, 128064),
                                                (32, 32, 9, 13, True, 128032), (128, 128, 8, 8, False, 64064),
                                                (64, 64, 11, 13, True, 64064), (32, 128, 9, 16, False, 64128),
                                                # even / odd k-step counts, ragged M, 64x128 tile, non-multiple-of-32 channels
                                                (16, 64, 9, 7, True, 64064), (48, 128, 6, 10, True, 64128),
                                                (128, 256, 8, 8, False, 64128), (32, 64, 12, 12, True, 128064),
-                                               (96, 128, 6, 10, True, 64032), (48, 64, 5, 9, True, 64032)])
+                                               (96, 128, 6, 10, True, 64032), (48, 64, 5, 9, True, 64032),
+                                               # wave-private-A structure (dcn_wp.hip): one / two / four phases per tap, ragged M
+                                               # (blocks of 128 pixels), two N tiles, out-of-range offsets
+                                               (64, 64, 16, 16, False, 9000064), (128, 64, 11, 13, True, 9000064),
+                                               (64, 128, 9, 7, True, 9000064), (256, 64, 5, 6, True, 9000064)])
 def test_dcn_v2_vs_scalar_oracle(C, Co, H, W, big, tile):
     from centerpose_amd import ops
     from oracle import dcn as odcn
@@ -387,10 +418,15 @@ def test_conv3x3_winograd_kernel(cin, cout, hw, B, nt):
         assert torch.isnan(buf[..., cout:]).all()      # nothing stored past Cout
 
 
-@pytest.mark.parametrize("B,H,W,hc,n2,act2", [(2, 32, 48, 256, 1, 2), (1, 37, 45, 256, 2, 0), (3, 8, 16, 128, 2, 0), (1, 19, 9, 64 * 5, 1, 2)])
+@pytest.mark.parametrize("B,H,W,hc,n2,act2", [(2, 32, 48, 256, 1, 2), (1, 37, 45, 256, 2, 0), (3, 8, 16, 128, 2, 0), (1, 19, 9, 64 * 5, 1, 2),
+                                               # second MFMA phase (round 3): hm_hp 17 (+ sigmoid), hps 34 = 32 MFMA + 2 register path,
+                                               # 33, a full 32, 3 (smallest MM case), ragged tiles, one channel tile only
+                                               (2, 32, 48, 256, 17, 2), (1, 37, 45, 256, 34, 0), (3, 8, 16, 128, 33, 0), (1, 19, 9, 64 * 5, 32, 0),
+                                               (2, 16, 16, 256, 3, 2), (1, 9, 21, 32, 34, 0), (16, 128, 128, 256, 34, 0)])
 def test_head3x3_1x1_fused(B, H, W, hc, n2, act2):
-    """One KeypointHead branch with <= 2 outputs in ONE launch (keypoint.py:14-37: conv3x3 + bias -> ReLU -> conv1x1 + bias; hm
-    gets its sigmoid, multi_pose.py:35-37): the 1x1 rides in the Winograd kernel's epilogue.  Ragged tiles, 1 and 2 outputs."""
+    """One KeypointHead branch in ONE launch (keypoint.py:14-37: conv3x3 + bias -> ReLU -> conv1x1 + bias; hm / hm_hp get their
+    sigmoid, multi_pose.py:35-37): <= 2 outputs ride in the Winograd kernel's epilogue registers, 3..34 outputs (hm_hp, hps) go
+    through a second MFMA phase over the LDS-resident ReLU'd tile.  Ragged tiles; the last case is the bench's own shape."""
     from centerpose_amd import ops
     g = torch.Generator().manual_seed(B * 100 + H + n2)
     x = torch.randn(B, 64, H, W, generator=g)

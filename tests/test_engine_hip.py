@@ -392,7 +392,7 @@ def test_full_size_batch_invariance_and_scaling_property(monkeypatch):
     del e2
     monkeypatch.setenv("CP_FUSE_HEADS", "1")
     ef = engine.Engine("dla_34", sd, 4, 512, 512)
-    assert sum(l.fn == "cp_head3x3_1x1_f32" for _, _, _, l in ef.launches) == 4
+    assert sum(l.fn == "cp_head3x3_1x1_f32" for _, _, _, l in ef.launches) == 6          # all six branches (round 3: hps / hm_hp too)
     fused = ef(x)
     torch.cuda.synchronize()
     for a, b in zip(fused, full):
