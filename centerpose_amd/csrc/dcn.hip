@@ -56,48 +56,44 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
 
     // ---- sampling records for every (tap, pixel) of this tile.  A thread keeps ONE pixel (tid % BM) and walks the taps
     // tid / BM, + 256 / BM, ...: the pixel's (b, oy, ox) decomposition (two integer divisions by run-time values, ~70 VALU) is
-    // done once instead of once per record, and the tap index is wave-uniform (scalar ky / kx).  Before this the prologue
-    // issued as many VALU instructions as the whole main loop of a 64-channel layer (PMC: 5 VALU per MFMA), and every
-    // VALU instruction costs matrix-pipe time.
+    // done once instead of once per record.  Round 3: PMC counts 1 434 VALU instructions per wave for a 64 -> 64 layer against
+    // 288 MFMAs -- 612 of them in the main loop and ~500 HERE (the disassembly had 170 per record: a vector integer division for
+    // the tap's (ky, kx), a full IEEE division in the sigmoid, twelve selects), and every VALU instruction costs matrix-pipe
+    // time.  Now: wave-uniform tap walk on the scalar unit, v_rcp_f32 for the sigmoid (1 ulp; the mask multiplies a value the
+    // path holds to 1e-4), row / column weights selected BEFORE the four products (4 selects instead of 12).
     {
         static_assert(IG_THREADS % BM == 0, "one pixel per thread");
+        constexpr int TS = IG_THREADS / BM;                               // taps advanced per pass
         const int pl = tid % BM, m = m0 + pl;
         const bool live = m < a.M;
         const int b = live ? m / HoWo : 0, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
         const float* omp = a.om + (size_t)(live ? m : 0) * a.omLd;
         const int by = oy * a.sy - a.py, bx = ox * a.sx - a.px, bpix = b * a.H * a.W;
         const float fH = (float)a.H, fW = (float)a.W;
-        for (int t = tap0 + tid / BM; t < tap1; t += IG_THREADS / BM) {
-            const int ky = t / a.kw, kx = t - ky * a.kw;                   // wave-uniform
-            float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            int code = 0;
-            if (live) {
-                const float offh = omp[2 * t], offw = omp[2 * t + 1];
-                float mk = omp[a.omMaskOff + t];
-                if (a.omSigmoid) mk = 1.0f / (1.0f + __expf(-mk));
-                const float h_im = (float)(by + ky * a.dily) + offh;
-                const float w_im = (float)(bx + kx * a.dilx) + offw;
-                if (h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW) {
-                    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
-                    const int h_high = h_low + 1, w_high = w_low + 1;
-                    const float lh = h_im - (float)h_low, lw = w_im - (float)w_low;
-                    const float hh = 1.f - lh, hw = 1.f - lw;
-                    const bool t_ok = h_low >= 0, b_ok = h_high <= a.H - 1, l_ok = w_low >= 0, r_ok = w_high <= a.W - 1;
-                    w4.x = (t_ok && l_ok) ? hh * hw * mk : 0.f;
-                    w4.y = (t_ok && r_ok) ? hh * lw * mk : 0.f;
-                    w4.z = (b_ok && l_ok) ? lh * hw * mk : 0.f;
-                    w4.w = (b_ok && r_ok) ? lh * lw * mk : 0.f;
-                    const int yl = t_ok ? h_low : 0, xl = l_ok ? w_low : 0;     // clamped, always in range
-                    const int dy = (t_ok && b_ok) ? 1 : 0, dx = (l_ok && r_ok) ? 1 : 0;
-                    code = (bpix + yl * a.W + xl) | (dx << 29) | (dy << 30);
-                    // when the top/left corner is out of range the record's base already IS the
-                    // bottom/right corner; its weight must then come from the matching slot:
-                    if (!t_ok) { w4.x = w4.z; w4.y = w4.w; w4.z = 0.f; w4.w = 0.f; }
-                    if (!l_ok) { w4.x = w4.y; w4.z = w4.w; w4.y = 0.f; w4.w = 0.f; }
-                }
-            }
-            s_w[t * BM + pl] = w4;
-            s_code[t * BM + pl] = code;
+        int t = tap0 + __builtin_amdgcn_readfirstlane(tid / BM);           // wave-uniform: BM is a multiple of the wave size
+        int ky = t / a.kw, kx = t - ky * a.kw;                             // scalar
+        for (; t < tap1; t += TS) {
+            const float offh = omp[2 * t], offw = omp[2 * t + 1];
+            float mk = omp[a.omMaskOff + t];
+            if (a.omSigmoid) mk = __builtin_amdgcn_rcpf(1.0f + __expf(-mk));
+            const float h_im = (float)(by + ky * a.dily) + offh;
+            const float w_im = (float)(bx + kx * a.dilx) + offw;
+            const bool valid = live && h_im > -1.f && w_im > -1.f && h_im < fH && w_im < fW;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1.f - lh, hw = 1.f - lw;
+            const int h_low = (int)hf, w_low = (int)wf;
+            const bool t_ok = h_low >= 0, b_ok = h_low < a.H - 1, l_ok = w_low >= 0, r_ok = w_low < a.W - 1;
+            // the record's base is the top-left corner clamped into the image: when the top (left) corner is out of range the base
+            // already IS the bottom (right) corner and takes its weight; the second row (column) is used only when both are in range
+            const bool dyb = t_ok && b_ok, dxb = l_ok && r_ok;
+            const float mv = valid ? mk : 0.f;
+            const float top = (t_ok ? hh : lh) * mv, bot = (dyb ? lh : 0.f) * mv;
+            const float lft = l_ok ? hw : lw, rgt = dxb ? lw : 0.f;
+            const int yl = min(max(h_low, 0), a.H - 1), xl = min(max(w_low, 0), a.W - 1);      // in range even for an invalid sample
+            s_w[t * BM + pl] = make_float4(top * lft, top * rgt, bot * lft, bot * rgt);
+            s_code[t * BM + pl] = (bpix + yl * a.W + xl) | ((dxb ? 1 : 0) << 29) | ((dyb ? 1 : 0) << 30);
+            kx += TS;
+            while (kx >= a.kw) { kx -= a.kw; ++ky; }
         }
     }
 
@@ -162,8 +158,22 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
         }
     };
 
+    // weight slice of k-step ks: the thread's byte offset inside the packed matrix is fixed, the k offset rides in the SCALAR
+    // base (global_load v, v_off, s[base]: no 64-bit address VALU per k-step)
+    unsigned boff[T::B_SLOTS];
+#pragma unroll
+    for (int s = 0; s < T::B_SLOTS; ++s) {
+        const int idx = tid + s * IG_THREADS;
+        boff[s] = ((unsigned)(n0 + (idx >> 2)) * (unsigned)a.K + (unsigned)(idx & 3) * 4u) * 4u;
+    }
+    auto load_b = [&](int ks) __attribute__((always_inline)) {
+        const char* wb = reinterpret_cast<const char*>(a.w) + (size_t)ks * (IG_BK * 4);      // uniform
+#pragma unroll
+        for (int s = 0; s < T::B_SLOTS; ++s)
+            if (T::B_F4 % IG_THREADS == 0 || tid + s * IG_THREADS < T::B_F4) br[s] = ig_ldg4(reinterpret_cast<const float*>(wb + boff[s]));
+    };
     load_a(); advance();
-    ig_load_b<T>(a, ks0 * IG_BK, n0, tid, br);
+    load_b(ks0);
     store_a(As0);
     ig_store_b<T>(Bs0, tid, br);
     __syncthreads();
@@ -172,7 +182,7 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
         const bool more = ks + 1 < nk;
         // the next step's gathers are issued from inside the MFMA block (half-way through the k-step)
         ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
-            if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br); }
+            if (more) { load_a(); advance(); load_b(ks + 1); }
         });
         // nothing that consumes the prefetched registers may be scheduled above the MFMAs (the blend /
         // zero-select would drag an s_waitcnt vmcnt in front of them and expose the whole load latency)
@@ -269,14 +279,6 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
                                 // interleave gather and MFMA phases better; the kernel is L1-gather-bound, not tile-reuse-bound)
     }
     int rc = 0;
-    if (tile == 9000064) {                       // wave-private-A structure (dcn_wp.hip)
-        CP_CHECK_ARG(a.ksplit == 1, "dcn_v2: split-K is implemented by dcn_igemm_kernel only");
-        rc = cp_launch_dcn_wp(a, s, 64);
-        CP_CHECK_ARG(rc >= 0, "dcn_v2: the wave-private-A kernel needs C %% 64 == 0 and ldw %% 64 == 0 (C=%d ldw=%d)", d->C, d->ldw);
-        if (rc) return rc;
-        CP_CHECK_LAUNCH("dcn_wp_kernel");
-        return 0;
-    }
     switch (tile) {
         case 128032: rc = launch_dcn<128, 32, 4, 1, 32>(a, s); break;
         case 128064: rc = launch_dcn<128, 64, 2, 2, 32>(a, s); break;

@@ -66,8 +66,6 @@ struct ConvArgs {
 int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s, int variant = 0);
 // conv3x3_wino.hip (a.w = Winograd-domain weights): same convention
 int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant = 0);
-// dcn_wp.hip: DCNv2 with wave-private A tiles, bn output channels per block; -1 = shape not eligible
-int cp_launch_dcn_wp(const ConvArgs& a, hipStream_t s, int bn);
 // conv3x3_wino.hip: [3x3 + bias + ReLU] + 1x1 (n2 <= 2 outputs, NCHW) of a head branch in one launch; -1 = shape not eligible
 int cp_launch_head3x3_1x1(const ConvArgs& a, const float* w2, const float* b2, float* out2, int n2, int ld2, int act2, hipStream_t s);
 
