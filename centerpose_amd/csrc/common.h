@@ -55,9 +55,28 @@ struct CpLdsGuard {
 #define CP_ACT_SIGMOID_ 2
 #define CP_ACT_HSWISH_ 3
 #define CP_ACT_HSIGMOID_ 4
+// ReLU as ONE v_max_f32.  fmaxf(v, 0.f) compiles to two (the compiler first quiets a possible signalling NaN with
+// v_max_f32 v, v, v); PMC ranks the conv kernels by "other VALU per MFMA" (profiles/r3_mfma_util.json) and every VALU instruction
+// takes issue cycles the matrix pipe then cannot use.  Same result for every input (max(0, NaN) = 0 either way).
+__device__ __forceinline__ float cp_relu(float v)
+{
+    float r;
+    asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
+typedef float cp_v2f __attribute__((ext_vector_type(2)));
+// v * sc + sh on a float4 as two v_pk_fma_f32 (same bits as four scalar fmas)
+__device__ __forceinline__ float4 cp_scale_shift4(float4 v, float4 sc, float4 sh)
+{
+    const cp_v2f lo = __builtin_elementwise_fma((cp_v2f){v.x, v.y}, (cp_v2f){sc.x, sc.y}, (cp_v2f){sh.x, sh.y});
+    const cp_v2f hi = __builtin_elementwise_fma((cp_v2f){v.z, v.w}, (cp_v2f){sc.z, sc.w}, (cp_v2f){sh.z, sh.w});
+    return make_float4(lo.x, lo.y, hi.x, hi.y);
+}
+__device__ __forceinline__ float4 cp_relu4(float4 v) { return make_float4(cp_relu(v.x), cp_relu(v.y), cp_relu(v.z), cp_relu(v.w)); }
+
 __device__ __forceinline__ float cp_act(float v, int act)
 {
-    if (act == CP_ACT_RELU_) return fmaxf(v, 0.f);
+    if (act == CP_ACT_RELU_) return cp_relu(v);
     if (act == CP_ACT_SIGMOID_) return 1.0f / (1.0f + __expf(-v));
     if (act == CP_ACT_HSWISH_) return v * fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;
     if (act == CP_ACT_HSIGMOID_) return fminf(fmaxf(v + 3.f, 0.f), 6.f) / 6.f;

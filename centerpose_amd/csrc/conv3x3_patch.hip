@@ -193,12 +193,12 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_patch_kernel(const Conv
                 float4 v = *reinterpret_cast<const float4*>(Cs + pl * LDC + c4 * 4);
                 const float4 sc = *reinterpret_cast<const float4*>(a.scale + n);
                 const float4 sh = *reinterpret_cast<const float4*>(a.shift + n);
-                v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y; v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                v = cp_scale_shift4(v, sc, sh);
                 if (a.res) {
                     const float4 rr = *reinterpret_cast<const float4*>(a.res + opix * a.resLd + n);
                     v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
                 }
-                if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+                if (relu) v = cp_relu4(v);
                 else if (sigm) {
                     v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
                     v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));

@@ -122,7 +122,7 @@ __device__ __forceinline__ void wg_output_tile(const ConvArgs& a, float* red, co
                 const size_t opix = itpix[it] + (size_t)aa * a.W;
                 wg_v4 v = __builtin_elementwise_fma(yv[aa], sc[it], sh[it]);
                 if (a_res) v += rr[it][aa];
-                if (relu) v = __builtin_elementwise_max(v, (wg_v4){0.f, 0.f, 0.f, 0.f});
+                if (relu) v = (wg_v4){cp_relu(v.x), cp_relu(v.y), cp_relu(v.z), cp_relu(v.w)};
                 else if (sigm) {
                     v.x = 1.0f / (1.0f + __expf(-v.x)); v.y = 1.0f / (1.0f + __expf(-v.y));
                     v.z = 1.0f / (1.0f + __expf(-v.z)); v.w = 1.0f / (1.0f + __expf(-v.w));
@@ -223,7 +223,7 @@ __device__ __forceinline__ void wg_output_tile_head(const ConvArgs& a, const WgH
 #pragma unroll
         for (int aa = 0; aa < 2; ++aa) {
             wg_v4 v = __builtin_elementwise_fma(yv[aa], sc[it], sh[it]);
-            v = __builtin_elementwise_max(v, (wg_v4){0.f, 0.f, 0.f, 0.f});        // the head's ReLU (keypoint.py:17,21,...)
+            v = (wg_v4){cp_relu(v.x), cp_relu(v.y), cp_relu(v.z), cp_relu(v.w)};  // the head's ReLU (keypoint.py:17,21,...)
 #pragma unroll
             for (int j = 0; j < N2; ++j) {
                 const wg_v4 w = w2r[it][j];
@@ -276,6 +276,11 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
     const int h = lane >> 5, m = lane & 31;
     const int NTILES = (a.Cout + 31) >> 5;             // 32-channel tiles in the packed U
     int t_ = ig_xcd_remap(blockIdx.x, gridDim.x), q_;
+    // split-C (a.ksplit = S > 1; small maps: a 512-channel 16x16 layer is 32 blocks of 32 stages on 256 CUs): block (tile, split)
+    // accumulates the stages [sp*n/S, (sp+1)*n/S) and stores RAW partial outputs to out + sp*M*outLd; cp_splitk_reduce_f32 sums the
+    // splits in a fixed order and applies scale / shift / activation (the output transform is linear, so partial sums add)
+    const int S = a.ksplit, sp = S > 1 ? t_ % S : 0;
+    if (S > 1) t_ /= S;
     q_ = wg_div(t_, gd.ntb, gd.mNtb); const int nb = t_ - q_ * gd.ntb; t_ = q_;
     q_ = wg_div(t_, gd.tilesX, gd.mTx); const int tx = t_ - q_ * gd.tilesX; t_ = q_;
     q_ = wg_div(t_, gd.tilesY, gd.mTy); const int ty = t_ - q_ * gd.tilesY;
@@ -364,10 +369,12 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][nt][nu][r] = 0.f;
 
-    stage_load(0);
+    const int nstage_all = C / KS;
+    const int st0 = sp * nstage_all / S, nstage = (sp + 1) * nstage_all / S;      // this block's stages [st0, nstage)
+    stage_load(st0 * KS);
 #pragma unroll
-    for (int s = 0; s < NB - 1; ++s) load_u(s, bq[s]);
-    stage_store(smem);
+    for (int s = 0; s < NB - 1; ++s) load_u(st0 * CPS + s, bq[s]);
+    stage_store(smem + (st0 & 1) * Geo::STAGE);
     __syncthreads();
 
     wg_v4 dAp[4], dBp[4];                     // raw rows carried across the MFMAs (PIPE only)
@@ -381,9 +388,8 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
     };
     constexpr bool PIPE = MT * NT >= 4;       // one wave per SIMD: nobody else hides the LDS round trip
     constexpr bool STORE_IN_BLOCK = U >= 2;   // patch hand-over (ds_write) from inside the last unit's MFMA block
-    const int nstage = C / KS;
 #pragma unroll 1
-    for (int st = 0; st < nstage; ++st) {
+    for (int st = st0; st < nstage; ++st) {
         const float* buf = smem + (st & 1) * Geo::STAGE;
         const bool more = st + 1 < nstage;
 #pragma unroll
@@ -459,7 +465,11 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             if (mt + nt) __syncthreads();
-            wg_output_tile(a, smem, acc[mt][nt], xi, h, m, tid, b, y0 + mt * 8, x0, nb * NT + nt, nb * NT + nt < NTILES);
+            if (S > 1) {
+                ConvArgs e = a;
+                e.out = a.out + (size_t)sp * ((size_t)a.B * a.H * a.W) * a.outLd;
+                wg_output_tile(e, smem, acc[mt][nt], xi, h, m, tid, b, y0 + mt * 8, x0, nb * NT + nt, nb * NT + nt < NTILES);
+            } else wg_output_tile(a, smem, acc[mt][nt], xi, h, m, tid, b, y0 + mt * 8, x0, nb * NT + nt, nb * NT + nt < NTILES);
         }
 }
 
@@ -690,9 +700,10 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
     const int ntiles = (a.Cout + 31) / 32;
     gd.ntb = (ntiles + NT - 1) / NT;
     gd.mNtb = wg_magic(gd.ntb); gd.mTx = wg_magic(gd.tilesX); gd.mTy = wg_magic(gd.tilesY);
-    const long long grid = (long long)a.B * gd.tilesX * gd.tilesY * gd.ntb;
+    const long long grid = (long long)a.B * gd.tilesX * gd.tilesY * gd.ntb * a.ksplit;
     const long long dmax = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
     if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd: grid %lld too large", grid); return 1; }
+    if (a.ksplit > a.srcC[0] / KS) { cp_set_error("conv3x3_winograd: ksplit=%d exceeds the %d channel stages", a.ksplit, a.srcC[0] / KS); return 1; }
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
     cp_note_kernel("conv3x3_wino_kernel<%d, %d, %d, %d>", MT, NT, KS, NB);
     return 0;
@@ -760,7 +771,7 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
     if (variant == 0) {
         const long long blocks_vs = (long long)a.B * cp_cdiv(a.H, 8) * cp_cdiv(a.W, WG_TW);
         // 64 input channels and >= 4 channel tiles (the head convs): V-stationary kernel, one block per spatial tile
-        if (a.srcC[0] == 64 && ntiles >= 4 && blocks_vs >= 512) variant = 6401;
+        if (a.srcC[0] == 64 && ntiles >= 4 && blocks_vs >= 512 && a.ksplit == 1) variant = 6401;
         else {
             variant = ntiles == 1 ? 11 : 12;
             // a launch that cannot give every CU a block takes the 32-channel block: twice the blocks (the V transform is
@@ -770,7 +781,7 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
         }
     }
     // 64xx: V-stationary kernel (C == 64), xx = number of channel-tile groups per spatial tile (0 -> 1)
-    if (variant >= 6400 && variant < 6500) return a.srcC[0] == 64 ? launch_wino_vs64<0>(a, s, variant - 6400, WgHead{}) : -1;
+    if (variant >= 6400 && variant < 6500) return (a.srcC[0] == 64 && a.ksplit == 1) ? launch_wino_vs64<0>(a, s, variant - 6400, WgHead{}) : -1;
     switch (variant) {
         case 11: return launch_wino<1, 1, 16, 2>(a, s);
         case 12: return launch_wino<1, 2, 16, 2>(a, s);

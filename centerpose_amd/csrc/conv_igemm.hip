@@ -228,6 +228,7 @@ struct cp_conv_desc {
     int inNCHW;   // 1: src[0] is the NCHW network input with srcC[0] (<16) channels (stem path)
     int tile;     // 0 = auto; otherwise BM*1000+BN of a specific instantiation (tuning / tests)
     int nsub;     // 0 / 1: one conv; 4: fused sub-pixel deconvolution (see ConvArgs::nsub)
+    int ksplit;   // cp_conv3x3_winograd_f32 only: S > 1 = split over the input channels, raw partial outputs to out[S][B*H*W][outLd]
 };
 
 extern "C" int cp_sizeof_conv_desc(void) { return (int)sizeof(cp_conv_desc); }
@@ -261,7 +262,7 @@ static int conv_args_from_desc(const cp_conv_desc* d, const float* const* src, c
     a.K = d->K; a.w = w; a.ldw = d->ldw; a.scale = scale; a.shift = shift;
     a.res = res; a.resLd = d->resLd; a.out = out; a.outLd = d->outLd; a.Cout = d->Cout;
     a.outNCHW = d->outNCHW; a.OH = d->OH; a.OW = d->OW; a.osy = d->osy; a.osx = d->osx; a.ooy = d->ooy; a.oox = d->oox;
-    a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1; a.ksplit = 1; a.nsub = d->nsub > 1 ? d->nsub : 1;
+    a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1; a.ksplit = d->ksplit > 1 ? d->ksplit : 1; a.nsub = d->nsub > 1 ? d->nsub : 1;
     CP_CHECK_ARG(a.M > 0 && (long long)d->B * d->H * d->W < (1ll << 31), "conv2d: bad problem size");
     for (int i = 0; i < d->nsrc && !d->inNCHW; ++i)
         CP_CHECK_ARG((long long)d->B * d->H * d->W * d->srcLd[i] * 4 < (1ll << 32), "conv2d: source %d exceeds 32-bit byte offsets", i);
@@ -274,6 +275,7 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
 {
     ConvArgs a;
     if (int rc = conv_args_from_desc(d, src, w, scale, shift, res, out, a)) return rc;
+    CP_CHECK_ARG(a.ksplit == 1, "conv2d: ksplit is implemented by cp_conv3x3_winograd_f32 and cp_dcn_v2_f32 only");
     hipStream_t s = (hipStream_t)stream;
 
     int tile = d->tile;
@@ -336,6 +338,7 @@ extern "C" int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const
     const float* srcs[1] = {src};
     CP_CHECK_ARG(d && d->nsrc == 1 && !d->inNCHW && w2 && b2 && out2, "head3x3_1x1: one NHWC source and the 1x1 operands expected");
     if (int rc = conv_args_from_desc(d, srcs, u, scale, shift, nullptr, out2, a)) return rc;
+    CP_CHECK_ARG(a.ksplit == 1, "head3x3_1x1: no split-C");
     const int rc = cp_launch_head3x3_1x1(a, w2, b2, out2, n2, ld2, act2, (hipStream_t)stream);
     CP_CHECK_ARG(rc >= 0, "head3x3_1x1: shape not eligible (C = 64, Cmid %% 32 == 0, ReLU, n2 <= 34, 16-byte aligned operands)");
     if (rc) return rc;
@@ -350,6 +353,8 @@ extern "C" int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, 
     const float* srcs[1] = {src};
     CP_CHECK_ARG(d && d->nsrc == 1 && !d->inNCHW, "conv3x3_winograd: one NHWC source expected");
     if (int rc = conv_args_from_desc(d, srcs, u, scale, shift, res, out, a)) return rc;
+    CP_CHECK_ARG(a.ksplit == 1 || (!res && d->act == CP_ACT_NONE && !d->outNCHW),
+                 "conv3x3_winograd: split-C writes raw NHWC partial outputs (no residual, no activation; scale = ones, shift = zeros)");
     const int rc = cp_launch_conv3x3_wino(a, (hipStream_t)stream, d->tile);
     CP_CHECK_ARG(rc >= 0, "conv3x3_winograd: shape not eligible (3x3, stride 1, pad 1, NHWC, C %% 16 == 0)");
     if (rc) return rc;

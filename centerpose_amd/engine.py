@@ -77,6 +77,7 @@ class PlanBuilder(nets.Graph):
         # CP_WINOGRAD=0 keeps every 3x3 on the direct (patch) kernel: A/B switch for tests and profiling
         self.winograd = os.environ.get("CP_WINOGRAD", "1") != "0"
         self.dcn_splitk = os.environ.get("CP_DCN_SPLITK", "1") != "0"      # split-K for the DCNv2 layers that cannot fill the CUs
+        self.wino_splitc = os.environ.get("CP_WINO_SPLITC", "1") != "0"    # split-C for Winograd launches on small maps
         self.fuse_heads = os.environ.get("CP_FUSE_HEADS", "1") != "0"      # 3x3 + 1x1 of a head branch in one launch
         self._pool_cache = {}
         self.outputs = None
@@ -143,6 +144,24 @@ class PlanBuilder(nets.Graph):
     def add(self, kind, name, flops, launch):
         self.launches.append((kind, name, flops * self.B, launch))
 
+    def add_wino(self, name, flops, x, wp, u, sc, sh, out, cout, act, res=None):
+        """One Winograd 3x3 launch -- or, for a map too small to fill the chip (ops.wino_ksplit) and no residual, a split-C
+        launch into a workspace of raw partial outputs plus the fixed-order reduction that applies scale / shift / activation."""
+        B, H, W, cin = x.shape
+        S = ops.wino_ksplit(B, H, W, cin, cout) if (self.wino_splitc and res is None) else 1
+        if S > 1:
+            ld, M = out.shape[3], B * H * W
+            ws = self.pool.take(S * M * ld)
+            wst = ws[: S * M * ld].view(S, M, ld)
+            ones, zeros = torch.ones(sc.numel(), device=self.dev), torch.zeros(sc.numel(), device=self.dev)
+            self.add("wino", name, flops, ops.conv2d_launch([x], wp, ones, zeros, wst, kh=3, kw=3, stride=1, pad=1, cout=cout, wino=u,
+                                                            ksplit=S))
+            self.add("sum", name + ".splitc", 0, ops.splitk_reduce_launch(wst, sc, sh, out, cout=cout, act=act))
+            self.pool.give(ws)
+            return
+        self.add("wino", name, flops, ops.conv2d_launch([x], wp, sc, sh, out, kh=3, kw=3, stride=1, pad=1, cout=cout, act=act, res=res,
+                                                        wino=u))
+
     # -- emit hooks ---------------------------------------------------------------------------
     def emit_conv(self, xs, conv, bn, bias, co, k, stride, pad, relu, res, stem):
         x = xs[0]
@@ -162,9 +181,13 @@ class PlanBuilder(nets.Graph):
         ci = sum(a.C for a in xs)
         cip = ci if stem else sum(a.t.shape[3] for a in xs)               # physical K per tap
         u = None if stem else self.wino(wp, cip, co, k, stride, pad, len(xs))
-        self.add("wino" if u is not None else "conv", conv, 2 * Ho * Wo * co * ci * k * k,
+        flops = 2 * Ho * Wo * co * ci * k * k
+        if u is not None:
+            self.add_wino(conv, flops, srcs[0], wp, u, sc, sh, out.t, out.t.shape[3], self.act_code(relu), rt)
+            return out
+        self.add("conv", conv, flops,
                  ops.conv2d_launch(srcs, wp, sc, sh, out.t, kh=k, kw=k, stride=stride, pad=pad, cout=out.t.shape[3],
-                                   act=self.act_code(relu), res=rt, in_nchw=stem, wino=u))
+                                   act=self.act_code(relu), res=rt, in_nchw=stem))
         return out
 
     def emit_maxpool(self, x, k, s, p):
@@ -189,8 +212,11 @@ class PlanBuilder(nets.Graph):
         wp = ops.pack_conv_weight(self.expand_in(self.w(conv + ".weight"), [x]))
         sc, sh = ops.fold_bn(co, self.bn(bn), self.w(conv + ".bias"), self.dev)
         uom = self.wino(wom, x.t.shape[3], 32)
-        self.add("wino" if uom is not None else "conv", conv + ".conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9,
-                 ops.conv2d_launch([x.t], wom, som, hom, om.t, kh=3, kw=3, stride=1, pad=1, cout=32, wino=uom))
+        if uom is not None:
+            self.add_wino(conv + ".conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9, x.t, wom, uom, som, hom, om.t, 32, ops.ACT_NONE)
+        else:
+            self.add("conv", conv + ".conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9,
+                     ops.conv2d_launch([x.t], wom, som, hom, om.t, kh=3, kw=3, stride=1, pad=1, cout=32))
         flops = 2 * x.H * x.W * co * x.C * 9
         S = ops.dcn_ksplit(self.B * x.H * x.W, wp.shape[0]) if self.dcn_splitk else 1
         if S > 1:

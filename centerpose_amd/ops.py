@@ -18,7 +18,7 @@ class ConvDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("nsrc",)] + [("srcC", ctypes.c_int * 4), ("srcLd", ctypes.c_int * 4)] + \
         [(n, ctypes.c_int) for n in ("B", "H", "W", "Ho", "Wo", "kh", "kw", "sy", "sx", "py", "px", "K", "ldw", "Cout",
                                      "resLd", "outLd", "outNCHW", "OH", "OW", "osy", "osx", "ooy", "oox", "act",
-                                     "inNCHW", "tile", "nsub")]
+                                     "inNCHW", "tile", "nsub", "ksplit")]
 
 
 class DcnDesc(ctypes.Structure):
@@ -182,13 +182,15 @@ def conv2d(srcs, wp, scale, shift, out, **kw):
 
 
 def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=ACT_NONE, res=None, out_nchw=False,
-                  in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0, wino=None, nsub=1):
+                  in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0, wino=None, nsub=1, ksplit=0):
     """Fused conv: out = act((sum_src conv(src)) * scale + shift [+ res]).
 
     nsub = 4: the four sub-pixel 2x2 convs of a dense ConvTranspose2d(k4,s2,p1) in one launch; wp = [4*ldw, K] (sub g = py*2+px),
     pad_yx = (1, 1), out_scatter = (2, 2, 0, 0).
     wino: Winograd-domain weights from `pack_wino_weight` -> the 3x3/s1/p1 launch goes through the fused
     F(2x2,3x3) kernel (cp_conv3x3_winograd_f32); `tile` then selects 32 (1) / 64 (2) channels per block.
+    ksplit = S > 1 (Winograd only): split over the input channels; `out` is the workspace [S, B*H*W, ld] of raw partial outputs
+    (scale = ones, shift = zeros, no act / residual) and `splitk_reduce_launch` finishes the layer.
 
     srcs: list of NHWC tensors (concatenated along C) or one NCHW tensor when in_nchw.
     out : NHWC [B,OH,OW,>=cout] (or NCHW [B,cout,OH,OW] when out_nchw).
@@ -215,7 +217,12 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
     d.K, d.ldw, d.Cout, d.nsub = wp.shape[1], wp.shape[0] // nsub, cout, nsub
     d.resLd = _ld(res) if res is not None else 0
     d.outNCHW = 1 if out_nchw else 0
-    if out_nchw:
+    d.ksplit = ksplit
+    if ksplit > 1:
+        assert wino is not None and res is None and act == ACT_NONE and not out_nchw and out.is_contiguous()
+        assert tuple(out.shape[:2]) == (ksplit, B * Ho * Wo) and out.shape[2] >= cout and out.shape[2] % 4 == 0
+        d.OH, d.OW, d.outLd = Ho, Wo, out.shape[2]
+    elif out_nchw:
         d.OH, d.OW, d.outLd = out.shape[2], out.shape[3], 0
         assert out.is_contiguous() and out.shape[1] == cout
     else:
@@ -302,6 +309,18 @@ def dcn_v2_launch(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, p
     else:
         d.outLd = 0 if out_nchw else _ld(out)
     return Launch("cp_dcn_v2_f32", d, [x, om, wp, scale, shift, out])
+
+
+def wino_ksplit(B, H, W, cin, cout):
+    """Split-C factor for a Winograd 3x3 launch without residual: the 8x16-pixel x 32-channel blocks of a small map cannot fill
+    256 CUs (512 -> 27 @16x16, B = 16: 32 blocks walking 32 channel stages).  S = smallest power of two that gives >= 512 blocks
+    while every split keeps >= 4 stages of 16 channels; 1 when the launch already has >= 256 blocks."""
+    blocks = B * ((H + 7) // 8) * ((W + 15) // 16) * ((cout + 31) // 32)
+    stages = cin // 16
+    S = 1
+    while blocks * S < 512 and stages // (2 * S) >= 4:
+        S *= 2
+    return S if blocks < 256 else 1
 
 
 def dcn_ksplit(M, ldw):

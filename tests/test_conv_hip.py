@@ -146,18 +146,24 @@ def test_maxpool(k, s, p):
     assert torch.equal(out.permute(0, 3, 1, 2).cpu(), ref)
 
 
-@pytest.mark.parametrize("f", [2, 4])
-def test_dw_deconv_add(f):
-    """IDAUp: up_i(proj(x)) + layers[i-1] (pose_dla_dcn.py:371-377)."""
+@pytest.mark.parametrize("f,B,C,H,W", [(2, 2, 32, 7, 9), (4, 2, 32, 7, 9), (2, 3, 64, 17, 5), (2, 2, 128, 8, 33)])
+def test_dw_deconv_add(f, B, C, H, W):
+    """IDAUp: up_i(proj(x)) + layers[i-1] (pose_dla_dcn.py:371-377); f = 2 and 4, strided (channel-padded) output views, with and
+    without the addend."""
     from centerpose_amd import ops
-    g = torch.Generator().manual_seed(f)
-    x = torch.randn(2, 32, 7, 9, generator=g)
-    w = torch.randn(32, 1, 2 * f, 2 * f, generator=g)
-    add = torch.randn(2, 32, 7 * f, 9 * f, generator=g)
-    ref = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=32) + add
-    out = torch.empty(2, 7 * f, 9 * f, 32, device="cuda")
+    g = torch.Generator().manual_seed(f + C + H)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, 2 * f, 2 * f, generator=g)
+    add = torch.randn(B, C, H * f, W * f, generator=g)
+    ref = F.conv_transpose2d(x, w, None, stride=f, padding=f // 2, groups=C) + add
+    buf = torch.full((B, H * f, W * f, C + 16), float("nan"), device="cuda")
+    out = buf[..., :C]
     ops.dw_deconv_add(_nhwc(x), ops.pack_dw_deconv_weight(w.cuda()), _nhwc(add), out, f)
     _close(out.permute(0, 3, 1, 2), ref, 1e-5)
+    assert torch.isnan(buf[..., C:]).all()
+    out2 = torch.empty(B, H * f, W * f, C, device="cuda")                     # no addend
+    ops.dw_deconv_add(_nhwc(x), ops.pack_dw_deconv_weight(w.cuda()), None, out2, f)
+    _close(out2.permute(0, 3, 1, 2), ref - add, 1e-5)
 
 
 def test_sum_up():
@@ -443,6 +449,39 @@ def test_head3x3_1x1_fused(B, H, W, hc, n2, act2):
     a = out.clone()
     ops.head3x3_1x1_launch(_nhwc(x), u, sc, sh, w1.reshape(n2, hc).contiguous().cuda(), b1.cuda(), out, hc=hc, act2=act2).run()
     assert torch.equal(a, out)             # fixed summation order: deterministic
+
+
+@pytest.mark.parametrize("B,H,W,cin,cout,S,act", [(2, 16, 16, 128, 27, 2, 0), (1, 13, 19, 512, 27, 8, 0), (3, 8, 16, 256, 64, 4, 1),
+                                                   (1, 32, 32, 96, 100, 3, 1)])
+def test_conv3x3_winograd_split_c(B, H, W, cin, cout, S, act):
+    """cp_conv_desc.ksplit: the Winograd kernel split over the input channels into raw partial outputs + cp_splitk_reduce_f32
+    (fixed-order sum, folded BN / bias, activation) against torch-CPU; ragged tiles, uneven stage split (96 channels in 3),
+    padded 27 -> 32 output channels; twice -> same bits; `ops.wino_ksplit` picks a legal factor for the DLA-34 offset convs."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + cin + S)
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bn = _rand_bn(g, cout)
+    ref = F.batch_norm(F.conv2d(x, w, None, 1, 1), bn[2], bn[3], bn[0], bn[1], False, 0.0, 1e-5)
+    ref = F.relu(ref) if act else ref
+    wp = ops.pack_conv_weight(w.cuda())
+    ld = ops.round_up(cout, 16)
+    u = ops.pack_wino_weight(wp, cin, ld)
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    ws = torch.full((S, B * H * W, ld), float("nan"), device="cuda")
+    out = torch.full((B, H, W, ld + 4), float("nan"), device="cuda")
+    n = sc.numel()
+    la = ops.conv2d_launch([_nhwc(x)], wp, torch.ones(n, device="cuda"), torch.zeros(n, device="cuda"), ws, kh=3, kw=3, stride=1, pad=1,
+                           cout=ld, wino=u, ksplit=S)
+    lb = ops.splitk_reduce_launch(ws, sc, sh, out[..., :ld], cout=ld, act=ops.ACT_RELU if act else ops.ACT_NONE)
+    la.run(); lb.run()
+    first = out.clone()
+    la.run(); lb.run()
+    assert torch.equal(first[..., :ld], out[..., :ld]) and torch.isnan(out[..., ld:]).all() and not torch.isnan(ws).any()
+    _close(out[..., :cout].permute(0, 3, 1, 2), ref, 1e-4)
+    for (b_, h_, c_) in ((16, 16, 512), (16, 32, 256), (16, 64, 128), (16, 128, 64), (1, 128, 64)):
+        s_ = ops.wino_ksplit(b_, h_, h_, c_, 27)
+        assert s_ >= 1 and (c_ // 16) // s_ >= 4 or s_ == 1
 
 
 def test_conv3x3_winograd_fuzz_vs_direct_kernel():

@@ -379,8 +379,11 @@ def test_full_size_batch_invariance_and_scaling_property(monkeypatch):
     sd = synth.make_state_dict("dla_34")
     x = synth.make_images(4).cuda()
     # bit-for-bit needs the same arithmetic per output in both plans: the fused head launch (one 1x1 summation order) switches on
-    # with the spatial tile count, i.e. at B = 4 but not at B = 2 -> compare like with like, then the fused plan within 1e-5
+    # with the spatial tile count, i.e. at B = 4 but not at B = 2, and the split-K / split-C factors of the small-map launches
+    # depend on the block count (round 3) -> compare like with like, then the default plan within 1e-5
     monkeypatch.setenv("CP_FUSE_HEADS", "0")
+    monkeypatch.setenv("CP_DCN_SPLITK", "0")
+    monkeypatch.setenv("CP_WINO_SPLITC", "0")
     e4 = engine.Engine("dla_34", sd, 4, 512, 512)
     full = [t.clone() for t in e4(x)]
     del e4
@@ -391,12 +394,16 @@ def test_full_size_batch_invariance_and_scaling_property(monkeypatch):
         assert all(torch.equal(f[2 * half:2 * half + 2], p) for f, p in zip(full, part))
     del e2
     monkeypatch.setenv("CP_FUSE_HEADS", "1")
+    monkeypatch.setenv("CP_DCN_SPLITK", "1")
+    monkeypatch.setenv("CP_WINO_SPLITC", "1")
     ef = engine.Engine("dla_34", sd, 4, 512, 512)
+    assert any(l.fn == "cp_splitk_reduce_f32" for _, _, _, l in ef.launches)
     assert sum(l.fn == "cp_head3x3_1x1_f32" for _, _, _, l in ef.launches) == 6          # all six branches (round 3: hps / hm_hp too)
     fused = ef(x)
     torch.cuda.synchronize()
     for a, b in zip(fused, full):
-        assert (a - b).abs().max().item() <= 1e-5 * max(1.0, b.abs().max().item())
+        # different summation orders (split partial sums, the fused heads' 1x1) through ~40 layers: ~2e-5 observed, bar 1e-3
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
     del ef
     g = torch.Generator().manual_seed(3)
     xin = torch.randn(16, 128, 128, 64, generator=g).cuda()
@@ -412,12 +419,13 @@ def test_full_size_batch_invariance_and_scaling_property(monkeypatch):
 
 
 @pytest.mark.parametrize("arch", ["res_50", "hrnet"])
-def test_full_size_b8_properties(arch):
+def test_full_size_b8_properties(arch, monkeypatch):
     """BASELINE.json configs[1] (res_50 512x512 batch 8) and configs[4]'s per-GPU shape (hrnet 512x512 batch 8): the oracle is
     too slow at this size, so size-independent properties -- determinism across hipGraph replays, batch invariance (B=8 in
     one plan == the same images through a B=4 plan, bit for bit), and image 0 against the CPU oracle within the 1e-3 bar."""
     from centerpose_amd import engine, synth
-    sd = synth.make_state_dict(arch)
+    monkeypatch.setenv("CP_WINO_SPLITC", "0")       # the split-C factor of a small-map launch depends on the batch: bit-for-bit batch
+    sd = synth.make_state_dict(arch)                # invariance is a property of plans with the same per-output arithmetic
     x = synth.make_images(8, seed=123)
     e8 = engine.Engine(arch, sd, 8, 512, 512)
     a = [t.clone() for t in e8(x.cuda())]

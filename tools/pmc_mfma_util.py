@@ -37,6 +37,25 @@ def main():
         res[k] = {"launches": n, "mfma_busy_cycles_per_launch": busy / n, "gui_active_per_launch": gui / n,
                   "mfma_pipe_utilisation": round(busy / (gui / 8.0 * 256 * 4), 4),
                   "mfma_pipe_utilisation_minus_dispatch_floor": round(busy / ((gui - n * floor) / 8.0 * 256 * 4), 4)}
+    # second pass: instruction counts.  SQ_INSTS_VALU includes the MFMA instructions; every other VALU instruction takes issue
+    # cycles on the SIMD that the matrix pipe then cannot use, so "other VALU per MFMA" ranks the kernels by how much
+    # of the gap to the MFMA peak is instruction overhead
+    d2 = d + "_insts"
+    cmd2 = cmd[:cmd.index("--pmc") + 1] + ["SQ_INSTS_VALU", "SQ_INSTS_MFMA", "SQ_INSTS_SALU", "SQ_INSTS_LDS"] + cmd[cmd.index("--kernel-trace"):]
+    cmd2[cmd2.index("-d") + 1] = d2
+    if os.environ.get("CP_PMC_REUSE", "0") != "1":
+        subprocess.run(cmd2, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=False, text=True)
+    ins = {}
+    for f in glob.glob(os.path.join(d2, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = re.sub(r"^void ", "", r["Kernel_Name"]).split("(")[0]
+            ins.setdefault(k, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    for k, c in ins.items():
+        if k in res and c.get("SQ_INSTS_MFMA") and sum(c["SQ_INSTS_MFMA"]) > 0:
+            mf, va = sum(c["SQ_INSTS_MFMA"]), sum(c.get("SQ_INSTS_VALU", [0]))
+            res[k]["other_valu_per_mfma"] = round((va - mf) / mf, 3)
+            res[k]["salu_per_mfma"] = round(sum(c.get("SQ_INSTS_SALU", [0])) / mf, 3)
+            res[k]["lds_per_mfma"] = round(sum(c.get("SQ_INSTS_LDS", [0])) / mf, 3)
     tot_busy = sum(v["mfma_busy_cycles_per_launch"] * v["launches"] for v in res.values())
     tot_gui = sum(v["gui_active_per_launch"] * v["launches"] for v in res.values())
     tot_n = sum(v["launches"] for v in res.values())
@@ -48,7 +67,9 @@ def main():
     json.dump(doc, open(out, "w"), indent=1)
     print("wrote", out, "all MFMA kernels:", doc["all_mfma_kernels_utilisation"])
     for k, v in doc["kernels"].items():
-        print("  %-56s %3d launches  util %.3f  (minus dispatch floor %.3f)" % (k[:56], v["launches"], v["mfma_pipe_utilisation"], v["mfma_pipe_utilisation_minus_dispatch_floor"]))
+        print("  %-56s %3d launches  util %.3f  (minus dispatch floor %.3f)  other VALU / MFMA %s  SALU / MFMA %s  LDS / MFMA %s" % (
+            k[:56], v["launches"], v["mfma_pipe_utilisation"], v["mfma_pipe_utilisation_minus_dispatch_floor"],
+            v.get("other_valu_per_mfma"), v.get("salu_per_mfma"), v.get("lds_per_mfma")))
 
 
 if __name__ == "__main__":
