@@ -232,17 +232,34 @@ void free_plan(cp_plan* pl)
 
 }  // namespace
 
+extern "C" uint32_t cp_fnv1a32(const void* data, size_t bytes)
+{
+    uint32_t h = 2166136261u;
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < bytes; ++i) { h ^= p[i]; h *= 16777619u; }
+    return h;
+}
+
 extern "C" int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_plan** out)
 {
     CP_CHECK_ARG(blob && out, "plan_create: null pointer");
     *out = nullptr;
     Reader r{static_cast<const unsigned char*>(blob), bytes};
-    CP_CHECK_ARG(bytes >= 48 && (memcmp(blob, "CPPLAN03", 8) == 0 || memcmp(blob, "CPPLAN02", 8) == 0),
+    const bool v4 = bytes >= 48 && memcmp(blob, "CPPLAN04", 8) == 0;
+    CP_CHECK_ARG(bytes >= 48 && (v4 || memcmp(blob, "CPPLAN03", 8) == 0 || memcmp(blob, "CPPLAN02", 8) == 0),
                  "plan_create: not a centerpose_amd plan (bad magic)");
     r.p = 8;
     const uint32_t abi = r.u32(), B = r.u32(), H = r.u32(), W = r.u32(), nbuf = r.u32(), nconst = r.u32(), nops = r.u32(),
                    nout = r.u32(), mlen = r.u32();
-    (void)r.u32();
+    const uint32_t want_sum = r.u32();
+    if (v4) {
+        // CPPLAN04: FNV-1a (32 bit) of everything behind the 48-byte header.  A plan file is a TRUSTED artifact, like a shared
+        // library: its descriptors drive device reads / writes and only their structure (arity, reference ranges, descriptor
+        // sizes) is validated, not every extent a kernel derives from them -- the checksum catches truncation and bit rot, it is
+        // no defence against a crafted file.
+        const uint32_t h = cp_fnv1a32(static_cast<const unsigned char*>(blob) + 48, bytes - 48);
+        CP_CHECK_ARG(h == want_sum, "plan_create: checksum mismatch (file %08x, computed %08x): truncated or corrupted plan", want_sum, h);
+    }
     CP_CHECK_ARG((int)abi == cp_abi_version(), "plan_create: plan was written for ABI %u, library has %d", abi, cp_abi_version());
     CP_CHECK_ARG(nbuf < (1u << 20) && nconst < (1u << 20) && nops < (1u << 20) && nout <= 64 && mlen < bytes,
                  "plan_create: corrupt header");
@@ -360,22 +377,31 @@ extern "C" int cp_plan_forward(cp_plan* pl, const float* images, void* stream)
     }
     if (!pl->use_graph) return run_all(pl, s);
     if (!pl->exec) {
-        // first call: one eager pass (sets kernel attributes, loads code objects), then capture the schedule once
+        // first call: one eager pass (sets kernel attributes, loads code objects), then capture the schedule once.  Every failure
+        // path releases what this attempt created (streams, graph): a later call starts from a clean handle instead of stacking
+        // new streams on leaked ones.
+        auto fail = [&](int rc) {
+            if (pl->graph) { (void)hipGraphDestroy(pl->graph); pl->graph = nullptr; }
+            if (pl->side_stream) { (void)hipStreamDestroy(pl->side_stream); pl->side_stream = nullptr; }
+            if (pl->cap_stream) { (void)hipStreamDestroy(pl->cap_stream); pl->cap_stream = nullptr; }
+            pl->exec = nullptr;
+            return rc;
+        };
         if (int rc = run_all(pl, s)) return rc;
         if (hipStreamSynchronize(s) != hipSuccess) { cp_set_error("plan_forward: warm-up pass failed"); return 2; }
-        if (hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) != hipSuccess) { cp_set_error("plan_forward: stream create"); return 2; }
+        if (hipStreamCreateWithFlags(&pl->cap_stream, hipStreamNonBlocking) != hipSuccess) { pl->cap_stream = nullptr; cp_set_error("plan_forward: stream create"); return fail(2); }
         bool two = false;
         for (const Op& o : pl->ops) two = two || o.stream != 0;
-        if (two && hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking) != hipSuccess) { cp_set_error("plan_forward: stream create"); return 2; }
-        if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { cp_set_error("plan_forward: begin capture"); return 2; }
+        if (two && hipStreamCreateWithFlags(&pl->side_stream, hipStreamNonBlocking) != hipSuccess) { pl->side_stream = nullptr; cp_set_error("plan_forward: stream create"); return fail(2); }
+        if (hipStreamBeginCapture(pl->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { cp_set_error("plan_forward: begin capture"); return fail(2); }
         std::vector<hipEvent_t> ev;
         const int rc = two ? run_two_streams(pl, pl->cap_stream, pl->side_stream, ev) : run_all(pl, pl->cap_stream);
-        hipError_t e = hipStreamEndCapture(pl->cap_stream, &pl->graph);
+        hipError_t e = hipStreamEndCapture(pl->cap_stream, &pl->graph);      // always end the capture, also after a failed enqueue
         for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
-        if (rc) return rc;
-        if (e != hipSuccess || !pl->graph) { cp_set_error("plan_forward: end capture: %s", hipGetErrorString(e)); return 2; }
+        if (rc) return fail(rc);
+        if (e != hipSuccess || !pl->graph) { cp_set_error("plan_forward: end capture: %s", hipGetErrorString(e)); return fail(2); }
         e = hipGraphInstantiate(&pl->exec, pl->graph, nullptr, nullptr, 0);
-        if (e != hipSuccess) { cp_set_error("plan_forward: graph instantiate: %s", hipGetErrorString(e)); pl->exec = nullptr; return 2; }
+        if (e != hipSuccess) { cp_set_error("plan_forward: graph instantiate: %s", hipGetErrorString(e)); return fail(2); }
         return 0;      // the warm-up pass already produced this call's outputs
     }
     hipError_t e = hipGraphLaunch(pl->exec, s);

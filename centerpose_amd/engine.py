@@ -66,9 +66,13 @@ class BufferPool:
 
 
 class PlanBuilder(nets.Graph):
-    def __init__(self, sd, B, device, sigmoid_heads=True):
+    def __init__(self, sd, B, device, sigmoid_heads=True, const_cache=None):
         super().__init__()
         self.sd, self.B, self.dev = sd, B, device
+        # shape-independent constants shared by the plans of one model (uploaded checkpoint tensors, Winograd-domain weights):
+        # with FIX_RES = false every new image size compiles a plan, and re-uploading / re-transforming 20 M parameters each time
+        # is most of that cost.  Keyed by parameter name; the owner (model.BackBoneWithHead) drops it with the weights.
+        self.const_cache = const_cache if const_cache is not None else {}
         self.pool = BufferPool(device, lambda: len(self.launches))
         if isinstance(sigmoid_heads, bool):
             sigmoid_heads = ("hm", "hm_hp") if sigmoid_heads else ()
@@ -130,15 +134,25 @@ class PlanBuilder(nets.Graph):
                 "hsigmoid": ops.ACT_HSIGMOID}[relu]
 
     def w(self, key):
-        return self.sd[key].to(self.dev, torch.float32)
+        hit = self.const_cache.get(("w", key))
+        if hit is None:
+            hit = self.const_cache[("w", key)] = self.sd[key].to(self.dev, torch.float32)
+        return hit
 
     def bn(self, name):
         return tuple(self.w("%s.%s" % (name, s)) for s in ("weight", "bias", "running_mean", "running_var"))
 
-    def wino(self, wp, cin, cout, k=3, stride=1, pad=1, nsrc=1):
-        """Winograd-domain weights for an eligible 3x3/s1/p1 layer, else None (direct kernel)."""
+    def wino(self, wp, cin, cout, k=3, stride=1, pad=1, nsrc=1, key=None):
+        """Winograd-domain weights for an eligible 3x3/s1/p1 layer, else None (direct kernel).  `key` (the layer's parameter
+        name): share the transformed weights between the plans of one model."""
         if self.winograd and ops.wino_eligible(cin, k, stride, pad, nsrc):
-            return ops.pack_wino_weight(wp, cin, cout)
+            ck = ("u", key, cin, cout)
+            hit = self.const_cache.get(ck) if key is not None else None
+            if hit is None:
+                hit = ops.pack_wino_weight(wp, cin, cout)
+                if key is not None:
+                    self.const_cache[ck] = hit
+            return hit
         return None
 
     def add(self, kind, name, flops, launch):
@@ -180,7 +194,7 @@ class PlanBuilder(nets.Graph):
         rt = res.t if res is not None else None
         ci = sum(a.C for a in xs)
         cip = ci if stem else sum(a.t.shape[3] for a in xs)               # physical K per tap
-        u = None if stem else self.wino(wp, cip, co, k, stride, pad, len(xs))
+        u = None if stem else self.wino(wp, cip, co, k, stride, pad, len(xs), key=conv)
         flops = 2 * Ho * Wo * co * ci * k * k
         if u is not None:
             self.add_wino(conv, flops, srcs[0], wp, u, sc, sh, out.t, out.t.shape[3], self.act_code(relu), rt)
@@ -211,7 +225,7 @@ class PlanBuilder(nets.Graph):
         out = self.buf(x.H, x.W, co)
         wp = ops.pack_conv_weight(self.expand_in(self.w(conv + ".weight"), [x]))
         sc, sh = ops.fold_bn(co, self.bn(bn), self.w(conv + ".bias"), self.dev)
-        uom = self.wino(wom, x.t.shape[3], 32)
+        uom = self.wino(wom, x.t.shape[3], 32, key=conv + ".conv_offset_mask")
         if uom is not None:
             self.add_wino(conv + ".conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9, x.t, wom, uom, som, hom, om.t, 32, ops.ACT_NONE)
         else:
@@ -315,7 +329,7 @@ class PlanBuilder(nets.Graph):
             b3 = torch.cat([self.w("%s.%s.0.bias" % (p, h)) for h, _ in nets.HEADS], 0)
             wp3 = ops.pack_conv_weight(w3)
             sc3, sh3 = ops.fold_bn(6 * hc, None, b3, self.dev)
-            u3 = self.wino(wp3, feat.t.shape[3], 6 * hc)
+            u3 = self.wino(wp3, feat.t.shape[3], 6 * hc, key=p + ".*.0")
             self.add("wino" if u3 is not None else "conv", p + ".*.0", 2 * H * W * 6 * hc * feat.C * 9,
                      ops.conv2d_launch([ft], wp3, sc3, sh3, mid.t, kh=3, kw=3, stride=1, pad=1, cout=6 * hc, act=ops.ACT_RELU, wino=u3))
         for i, (h, n) in enumerate(nets.HEADS):
@@ -326,7 +340,7 @@ class PlanBuilder(nets.Graph):
             if per_head:
                 wp3h = ops.pack_conv_weight(self.expand_in(self.w("%s.%s.0.weight" % (p, h)), [feat]))
                 sc3h, sh3h = ops.fold_bn(hc, None, self.w("%s.%s.0.bias" % (p, h)), self.dev)
-                u3h = self.wino(wp3h, feat.t.shape[3], hc)
+                u3h = self.wino(wp3h, feat.t.shape[3], hc, key="%s.%s.0" % (p, h))
                 if u3h is not None and self.fuse_heads and ops.head3x3_1x1_eligible(ft, hc, n):
                     # the 1x1 rides in the Winograd kernel (<= 2 outputs: epilogue registers; hps / hm_hp: a second MFMA phase
                     # over the LDS-resident tile): the [B,H,W,hc] intermediate (268 MB at B = 16) is neither written nor read back
@@ -390,7 +404,7 @@ class Engine:
     """Static-shape inference engine for one (arch, batch, H, W)."""
 
     def __init__(self, arch, state_dict, batch, height=512, width=512, device="cuda", head_conv=None,
-                 sigmoid_heads=True, use_graph=True, decode_k=None):
+                 sigmoid_heads=True, use_graph=True, decode_k=None, const_cache=None, sched_cache=None):
         if not torch.cuda.is_available():
             raise _lib.CenterposeHipError("Engine needs a HIP device; there is no CPU fallback")
         _lib.lib()
@@ -407,13 +421,14 @@ class Engine:
                 raise ValueError("parameter %s has shape %s, expected %s" % (k, tuple(sd[k].shape), shp))
         with torch.cuda.device(self.device):
             self.input = torch.zeros((batch, 3, height, width), dtype=torch.float32, device=self.device)
-            pb = PlanBuilder(sd, batch, self.device, sigmoid_heads)
+            pb = PlanBuilder(sd, batch, self.device, sigmoid_heads, const_cache)
             pb.network(self.arch, Act(height, width, 3, self.input), head_conv)
         self.launches = pb.launches
         self.outputs = pb.outputs
         self.flops_per_image = pb.flops
         self.activation_bytes = pb.bytes_alloc
         self.graph = None
+        self.sched_cache = sched_cache # {launch names -> (order, streams)}: a model's plans for other image sizes reuse a schedule
         self.capture_mode = None       # how the hipGraph was captured: "2-stream" / "single-stream" / "single-stream-fallback"
         self.use_graph = use_graph
         self.dets, self.decode_k = None, None
@@ -446,11 +461,12 @@ class Engine:
         return outs, self.dets
 
     # -- on-disk plan --------------------------------------------------------------
-    def save_plan(self, path):
+    def save_plan(self, path, deterministic=False):
         """Write the compiled plan (packed weights + launch schedule) so a later start skips checkpoint parsing,
-        BN folding and weight packing: `Engine.from_plan(path)`."""
+        BN folding and weight packing: `Engine.from_plan(path)`.  deterministic: schedule from the roofline model instead of
+        measured durations -- the same checkpoint then gives the same bytes on every run (cacheable by hash)."""
         from . import plan
-        return plan.save_plan(self, path)
+        return plan.save_plan(self, path, deterministic)
 
     @classmethod
     def from_plan(cls, path, device="cuda", use_graph=True):
@@ -496,12 +512,20 @@ class Engine:
         under-filled small-map launches: dla_34 B=16 8.19 -> 7.97 ms, hrnet B=8 6.96 -> 6.27 ms per forward, outputs
         bit-identical (tools/sched_try.py).  Any result is a topological order of the same DAG, so eager execution of
         the re-ordered list computes the same values.  Sets `self.launches` (new order) and `self.stream_plan`."""
-        if durations is None:
-            durations = [r["ms"] for r in self.profile_in_sequence(iters=3)]
-        order, assign, makespan = list_schedule(self.dependencies(), durations, nstreams)
+        order, assign, makespan = self.plan_schedule(durations, nstreams)
         self.launches = [self.launches[i] for i in order]
         self.stream_plan = [assign[i] for i in order]
         return makespan
+
+    def plan_schedule(self, durations=None, nstreams=2):
+        """The schedule `schedule()` would apply, WITHOUT touching the engine: (order, stream of launch i, simulated makespan).
+        durations: per-launch times; None = measured now (`profile_in_sequence`); "model" = a deterministic roofline estimate
+        (max(flops / 100 TFLOP/s, bytes / 4 TB/s) + 5 us), for plan files that must be byte-identical from run to run."""
+        if durations is None:
+            durations = [r["ms"] for r in self.profile_in_sequence(iters=3)]
+        elif isinstance(durations, str) and durations == "model":
+            durations = [max(f / 100e12, nb / 4e12) * 1e3 + 5e-3 for (_, _, f, _), nb in zip(self.launches, self.launch_bytes())]
+        return list_schedule(self.dependencies(), durations, nstreams)
 
     def _run_branches(self, main, nstreams, deps, assign=None):
         """Enqueue the schedule on `nstreams` streams (main + side streams): independent branches of the graph
@@ -574,7 +598,19 @@ class Engine:
         self.capture_mode = "single-stream"
         if nstreams > 1:
             if getattr(self, "stream_plan", None) is None and nstreams == 2 and os.environ.get("CP_SCHED", "1") != "0":
-                self.schedule()
+                # the measured critical-path schedule costs three eager passes: a model that compiles a plan per image size
+                # (FIX_RES = false) reuses the order / stream placement of an earlier plan with the same launch list
+                names = tuple(n for _, n, _, _ in self.launches)
+                hit = self.sched_cache.get(names) if self.sched_cache is not None else None
+                if hit is not None:
+                    self.launches = [self.launches[i] for i in hit[0]]
+                    self.stream_plan = list(hit[1])
+                else:
+                    order, assign, _ = self.plan_schedule()
+                    self.launches = [self.launches[i] for i in order]
+                    self.stream_plan = [assign[i] for i in order]
+                    if self.sched_cache is not None:
+                        self.sched_cache[names] = (order, list(self.stream_plan))
             deps = self.dependencies()
             try:
                 g = torch.cuda.CUDAGraph()

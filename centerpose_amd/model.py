@@ -27,6 +27,7 @@ class BackBoneWithHead:
         # distinct image size a new shape: the cache is bounded (CP_ENGINE_CACHE, default 4) and an evicted plan's
         # buffers, constants and hipGraph are released, so an evaluate.py-style loop over COCO does not grow.
         self._engines = OrderedDict()
+        self._const_cache, self._sched_cache = {}, {}     # shared by this model's plans: uploaded / transformed weights, schedules
         self.max_engines = max(1, int(os.environ.get("CP_ENGINE_CACHE", "4")))
         self.use_graph = True
 
@@ -37,6 +38,7 @@ class BackBoneWithHead:
     def load_state_dict(self, sd, strict=False):
         self._sd = {k: v.detach().cpu() for k, v in sd.items()}
         self._engines.clear()
+        self._const_cache.clear()
 
     def to(self, device):
         self.device = torch.device(device)
@@ -44,6 +46,7 @@ class BackBoneWithHead:
             from ._lib import CenterposeHipError
             raise CenterposeHipError("centerpose_amd models run on the HIP device only")
         self._engines.clear()
+        self._const_cache.clear()
         return self
 
     def eval(self):
@@ -59,7 +62,7 @@ class BackBoneWithHead:
             self._engines.popitem(last=False)            # drop the least recently used plan before building the next one
         eng = engine.Engine(self.arch, self._sd, B, H, W, device=self.device, head_conv=self.head_conv,
                             sigmoid_heads=("hm",) + (("hm_hp",) if self.sigmoid_hm_hp else ()), use_graph=self.use_graph,
-                            decode_k=decode_k)
+                            decode_k=decode_k, const_cache=self._const_cache, sched_cache=self._sched_cache)
         self._engines[key] = eng
         return eng
 

@@ -11,12 +11,14 @@ they name -- in a flat little-endian binary layout with no pickled objects, so t
 
 Layout (all integers little-endian; offsets in bytes from the start of the file):
 
-    char[8]  magic "CPPLAN03"  ("CPPLAN02" files are still read: the same layout with stream = 0 in every op)
+    char[8]  magic "CPPLAN04"  ("CPPLAN03" files are still read: no checksum; "CPPLAN02": also stream = 0 in every op)
     u32      abi            cp_abi_version() of the library that wrote it (descriptor struct layouts)
     u32      B, H, W        network input [B,3,H,W]
     u32      nbuf, nconst, nops, nout
     u32      meta_len       JSON (utf-8): {"arch", "flops_per_image", "ops": [{"kind", "name", "flops"}, ...]}
-    u32      0              (pads the fixed header to 48 bytes: everything below is 8-byte aligned)
+    u32      checksum       FNV-1a (32 bit) of every byte behind this 48-byte header (CPPLAN04; 0 in older files).  It catches
+                            truncation and bit rot.  A plan file is a TRUSTED artifact like a shared library: readers validate its
+                            structure (arity, reference ranges, descriptor sizes), not every extent a kernel derives from it.
     u8[meta_len], zero padded to a multiple of 8
     u64[nbuf]               activation / output storages, float32 elements (allocated at load time)
     {u64 numel, u64 offset}[nconst]      packed weights, folded scale/shift, Winograd U: raw float32 at `offset`
@@ -39,8 +41,25 @@ import torch
 
 from . import _lib, ops
 
-MAGIC = b"CPPLAN03"
+MAGIC = b"CPPLAN04"
+MAGIC_V3 = b"CPPLAN03"
 MAGIC_V2 = b"CPPLAN02"
+
+
+def checksum(data):
+    """FNV-1a (32 bit) of a bytes-like object, computed by the library (`cp_fnv1a32`, host code: a plan is tens of MB and the
+    hash is sequential)."""
+    mv = memoryview(data).cast("B")
+    n = len(mv)
+    if n == 0:
+        return 2166136261
+    buf = (ctypes.c_ubyte * n).from_buffer_copy(mv) if mv.readonly else (ctypes.c_ubyte * n).from_buffer(mv)
+    L = _lib.lib()
+    L.cp_fnv1a32.restype = ctypes.c_uint32
+    L.cp_fnv1a32.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    return int(L.cp_fnv1a32(ctypes.addressof(buf), n))
+
+
 REF_NULL, REF_BUF, REF_CONST = 0, 1, 2
 FN_NAMES = {v: k for k, v in ops.FN_IDS.items()}
 DESC_TYPES = {"cp_conv2d_f32": ops.ConvDesc, "cp_conv3x3_winograd_f32": ops.ConvDesc, "cp_dcn_v2_f32": ops.DcnDesc,
@@ -107,6 +126,7 @@ def serialize(launches, meta, inp, outputs, abi, streams=None):
     mjs = json.dumps(mj).encode()
     B, _, H, W = inp.shape
     head = MAGIC + struct.pack("<IIIIIIIIII", abi, B, H, W, len(enc.buf_numel), len(enc.consts), len(launches), len(outputs), len(mjs), 0)
+    assert len(head) == 48
     head += _pad8(mjs) + struct.pack("<%dQ" % len(enc.buf_numel), *enc.buf_numel)
     body = _pack_ref(in_ref) + out_blob + b"".join(op_blobs)
     table_len = 16 * len(enc.consts)
@@ -121,18 +141,26 @@ def serialize(launches, meta, inp, outputs, abi, streams=None):
     for off, c in data:
         out += b"\0" * (off - len(out))
         out += c.numpy().tobytes()
+    struct.pack_into("<I", out, 44, checksum(memoryview(out)[48:]))
     return bytes(out)
 
 
-def save_plan(engine, path):
-    """Write `engine`'s compiled plan (packed constants + launch schedule) to `path`.  The schedule is the two-stream one
-    (`Engine.schedule`, measured once here if the engine has not captured yet), so the C runtime replays what Python replays."""
+def save_plan(engine, path, deterministic=False):
+    """Write `engine`'s compiled plan (packed constants + launch schedule) to `path`.  The schedule is the two-stream one, so the
+    C runtime replays what Python replays: the engine's own if it has one; otherwise one is made here -- applied to the engine
+    when it has not captured yet (it will then capture the same order), computed on the side when a graph already exists (an
+    engine captured with CP_STREAMS=1 / CP_SCHED=0 keeps its launch order, `stream_of_launch` and profile indices: ADVICE r2)."""
     import os
-    if getattr(engine, "stream_plan", None) is None and os.environ.get("CP_SCHED", "1") != "0" and os.environ.get("CP_STREAMS", "2") == "2":
-        engine.schedule()
+    launches, streams = engine.launches, getattr(engine, "stream_plan", None)
+    if (streams is None or deterministic) and os.environ.get("CP_SCHED", "1") != "0" and os.environ.get("CP_STREAMS", "2") == "2":
+        if engine.graph is None and not deterministic:
+            engine.schedule()
+            launches, streams = engine.launches, engine.stream_plan
+        else:
+            order, assign, _ = engine.plan_schedule("model" if deterministic else None)
+            launches, streams = [engine.launches[i] for i in order], [assign[i] for i in order]
     meta = {"arch": engine.arch, "flops_per_image": int(engine.flops_per_image)}
-    blob = serialize(engine.launches, meta, engine.input, engine.outputs, int(_lib.lib().cp_abi_version()),
-                     getattr(engine, "stream_plan", None))
+    blob = serialize(launches, meta, engine.input, engine.outputs, int(_lib.lib().cp_abi_version()), streams)
     with open(path, "wb") as f:
         f.write(blob)
     return len(blob)
@@ -159,11 +187,13 @@ class _Reader:
 def parse(blob):
     """bytes -> dict(abi, B, H, W, meta, buffers, consts [(numel, offset)], input ref, outputs [(ref, shape)],
     ops [(fn name, desc bytes, refs, ints, out_index, stream)]).  Host only; validates structure, raises ValueError."""
-    if len(blob) < 48 or bytes(blob[:8]) not in (MAGIC, MAGIC_V2):
+    if len(blob) < 48 or bytes(blob[:8]) not in (MAGIC, MAGIC_V3, MAGIC_V2):
         raise ValueError("not a centerpose_amd plan file (magic %r)" % bytes(blob[:8]))
     r = _Reader(blob)
     r.p = 8
-    abi, B, H, W, nbuf, nconst, nops, nout, mlen, _ = r.take("<IIIIIIIIII")
+    abi, B, H, W, nbuf, nconst, nops, nout, mlen, csum = r.take("<IIIIIIIIII")
+    if bytes(blob[:8]) == MAGIC and checksum(memoryview(blob)[48:]) != csum:
+        raise ValueError("plan file: checksum mismatch (truncated or corrupted)")
     try:
         meta = json.loads(r.raw(mlen).decode())
     except ValueError:
@@ -240,6 +270,8 @@ def load_plan(path, device="cuda", use_graph=True):
         eng.flops_per_image = p["meta"]["flops_per_image"]
         eng.activation_bytes = 4 * sum(p["buffers"])
         eng.graph = None
+        eng.sched_cache = None
+        eng.capture_mode = None
         eng.use_graph = use_graph
         eng.dets, eng.decode_k = None, None
         dec = [l for _, _, _, l in launches if l.fn == "cp_decode_assign_f32"]

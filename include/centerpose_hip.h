@@ -209,6 +209,8 @@ int cp_decode_assign_f32(const float* wh, const float* kps, const float* reg, co
  *   hm and hm_hp are already sigmoided (multi_pose.py:35-37 fused into the head epilogue).
  * cp_plan_process: forward + cp_multi_pose_decode_f32 -> dets DEVICE float32 [B,K,5+3J]. */
 typedef struct cp_plan cp_plan;
+/* FNV-1a (32 bit) of a host buffer: the checksum a CPPLAN04 file carries over everything behind its 48-byte header */
+unsigned int cp_fnv1a32(const void* data, size_t bytes);
 int cp_plan_load(const char* path, int use_graph, cp_plan** out);
 int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_plan** out);
 int cp_plan_info(const cp_plan* plan, int* B, int* H, int* W, int* n_outputs, int* n_launches);

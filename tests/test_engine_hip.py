@@ -517,3 +517,39 @@ def test_timed_configuration_parity(arch, B):
         assert os.path.exists(BENCH_LINE), "profiles/bench_line.json (the committed `python bench.py` line) is missing"
         timed = sorted(json.load(open(BENCH_LINE))["roofline"]["kernels"])
         assert kernels == timed, "tested kernels %s != timed kernels %s -- refresh profiles/bench_line.json" % (kernels, timed)
+
+
+def test_model_shares_constants_and_schedules_between_shapes():
+    """FIX_RES = false compiles a plan per image size (model.BackBoneWithHead.engine_for).  The plans of one model share the
+    uploaded / Winograd-transformed weights and, for an identical launch list, the measured two-stream schedule --
+    and compute the same bits as a stand-alone engine of that shape; loading new weights drops the shared constants."""
+    from centerpose_amd import config, engine, model, synth
+    cfg = config.get_cfg("dla_34", TEST__FLIP_TEST=False)
+    m = model.create_model(cfg.MODEL.NAME, cfg.MODEL.HEAD_CONV, cfg).to("cuda")
+    x1, x2 = synth.make_images(1, 128, 160, seed=1).cuda(), synth.make_images(1, 160, 128, seed=2).cuda()
+    o1 = [t.clone() for t in m(x1)]
+    n_const, n_sched = len(m._const_cache), len(m._sched_cache)
+    assert n_const > 100 and n_sched == 1
+    e1 = m._engines[(1, 128, 160)]
+    o2 = [t.clone() for t in m(x2)]
+    e2 = m._engines[(1, 160, 128)]
+    assert len(m._const_cache) == n_const                     # nothing was uploaded or transformed again
+    same = sorted(n for _, n, _, _ in e1.launches) == sorted(n for _, n, _, _ in e2.launches)     # (split factors may differ by shape)
+    assert len(m._sched_cache) == (n_sched if same else n_sched + 1)
+    if same:
+        assert e2.stream_plan == e1.stream_plan and [n for _, n, _, _ in e1.launches] == [n for _, n, _, _ in e2.launches]
+    m._engines.pop((1, 128, 160))                               # evicted plan, same shape again: schedule comes from the cache
+    o1b = m(x1)
+    assert len(m._sched_cache) == (n_sched if same else n_sched + 1) and len(m._const_cache) == n_const
+    assert all(torch.equal(a, b) for a, b in zip(o1, o1b))
+    u1 = {id(t) for _, _, _, l in e1.launches for t in l.tensors if t is not None}
+    assert sum(id(t) in u1 for _, _, _, l in e2.launches for t in l.tensors if t is not None) > 50      # the same constant tensors
+    ref = engine.Engine("dla_34", m.state_dict(), 1, 160, 128, head_conv=cfg.MODEL.HEAD_CONV, sigmoid_heads=("hm", "hm_hp"))(x2)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(o2, ref))
+    assert all(torch.equal(a, b) for a, b in zip(o1, m(x1)))
+    m.load_state_dict(synth.make_state_dict("dla_34", seed=5))
+    assert not m._const_cache and not m._engines
+    o3 = m(x1)
+    torch.cuda.synchronize()
+    assert not torch.equal(o3[0], o1[0])

@@ -174,10 +174,19 @@ def test_plan_format_serialize_parse_and_schema():
     d = ops.ConvDesc.from_buffer_copy(p["ops"][2][1])
     assert (d.kh, d.Cout, d.outNCHW, d.act) == (1, 1, 1, ops.ACT_SIGMOID)
     # execution streams: default all on the main stream; a schedule is stored per op; format 02 files (no schedule) still parse
-    assert blob[:8] == b"CPPLAN03" and [o[5] for o in p["ops"]] == [0, 0, 0]
+    assert blob[:8] == b"CPPLAN04" and [o[5] for o in p["ops"]] == [0, 0, 0]
+    # CPPLAN04 carries an FNV-1a checksum of everything behind the 48-byte header: one flipped constant byte is caught ...
+    flipped = bytearray(blob)
+    flipped[-3] ^= 0x10
+    with pytest.raises(ValueError, match="checksum"):
+        plan.parse(memoryview(bytes(flipped)))
+    assert plan.checksum(b"") == 2166136261 and plan.checksum(b"a") == 0xE40C292C          # FNV-1a test vectors
+    # ... older files (no checksum) still parse; the structural checks below run on such a file so that they, not the checksum, fire
+    blob = b"CPPLAN03" + blob[8:]
     blob2 = plan.serialize([("conv", "a", 10, l1), ("pool", "p", 0, l2), ("conv", "h", 5, l3)],
                            {"arch": "x", "flops_per_image": 3}, inp, [out], 2, streams=[0, 1, 0])
     assert [o[5] for o in plan.parse(memoryview(blob2))["ops"]] == [0, 1, 0] and len(blob2) == len(blob)
+    blob2 = b"CPPLAN03" + blob2[8:]
     assert [o[:5] for o in plan.parse(memoryview(b"CPPLAN02" + blob[8:]))["ops"]] == [o[:5] for o in p["ops"]]
     with pytest.raises(ValueError):                             # a third stream does not exist
         bad = bytearray(blob2)
