@@ -43,7 +43,8 @@ template <int MT, int KS> struct WgGeo {
     static constexpr int STAGE = CGS * CG;               // floats per stage buffer
     static constexpr int F4 = PH * WG_PW * CGS;          // float4 per stage
     static constexpr int SLOTS = (F4 + IG_THREADS - 1) / IG_THREADS;
-    static constexpr int SMEM_FLOATS = 2 * STAGE > WG_RED ? 2 * STAGE : WG_RED;
+    static constexpr int MAIN_FLOATS = 2 * STAGE > WG_RED ? 2 * STAGE : WG_RED;
+    static constexpr int SMEM_FLOATS = MAIN_FLOATS + 16;      // + 64 bytes of zeros: the accumulators are initialised by LDS reads
 };
 
 // launch geometry; block-index decomposition uses host-made magic numbers: q = mulhi(n, ceil(2^32/d)) is exact
@@ -359,23 +360,35 @@ __global__ __launch_bounds__(IG_THREADS, (MT * NT == 1 && NB == 2) ? 3 : (MT * N
             for (int nu = 0; nu < 4; ++nu) dst[nt][nu] = ig_ldg4(ub[nt] + (size_t)kk * 1024 + nu * 256);
     };
 
-    f32x16 acc[MT][NT][4];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][nu][r] = 0.f;
-
     const int nstage_all = C / KS;
     const int st0 = sp * nstage_all / S, nstage = (sp + 1) * nstage_all / S;      // this block's stages [st0, nstage)
+    __builtin_assume(st0 < nstage);            // (the launcher checks ksplit <= C / KS) no second copy of the prologue for an empty loop
     stage_load(st0 * KS);
 #pragma unroll
     for (int s = 0; s < NB - 1; ++s) load_u(st0 * CPS + s, bq[s]);
     stage_store(smem + (st0 & 1) * Geo::STAGE);
+    if (tid < 4) *reinterpret_cast<float4*>(smem + Geo::MAIN_FLOATS + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
     __syncthreads();
+    // 64 * MT * NT accumulator registers start at zero.  As v_mov_b32 that is 128 VALU instructions per wave (the compiler even emitted
+    // them twice, once for the path around the loop), a quarter of what a 128-channel layer's main loop issues -- and every VALU
+    // instruction takes issue cycles the matrix pipe cannot use.  Broadcast ds_read_b128 of a zeroed LDS line cost none.
+    f32x16 acc[MT][NT][4];
+    {
+        const wg_v4* zp = reinterpret_cast<const wg_v4*>(smem + Geo::MAIN_FLOATS);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+                    for (int r4 = 0; r4 < 4; ++r4) {
+                        wg_v4 z = zp[r4];
+                        asm volatile("" : "+v"(z));          // four distinct reads: the compiler must not fold them into one + copies
+                        acc[mt][nt][nu][4 * r4] = z.x; acc[mt][nt][nu][4 * r4 + 1] = z.y;
+                        acc[mt][nt][nu][4 * r4 + 2] = z.z; acc[mt][nt][nu][4 * r4 + 3] = z.w;
+                    }
+    }
 
     wg_v4 dAp[4], dBp[4];                     // raw rows carried across the MFMAs (PIPE only)
     auto read_d = [&](const float* buf, int ch, int mt, wg_v4 (&dA)[4], wg_v4 (&dB)[4]) __attribute__((always_inline)) {

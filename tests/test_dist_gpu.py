@@ -23,7 +23,7 @@ def _bench(env_extra):
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--batch", "2",
-                        "--no-cpu-baseline", "--no-profile"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+                        "--no-cpu-baseline", "--no-profile", "--gather-check"], capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -36,6 +36,11 @@ def test_bench_self_launches_two_ranks():
     assert line["n_gpus"] == 2 and line["ranks"] == 2 and line["backend"] == ("nccl" if multi else "gloo")
     assert line["config"]["global_batch"] == 4 and line["scaling"] == "weak" and line["value"] > 0
     assert line["steps"] == 3 and abs(line["value"] - 4 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-3
+    # round 3: what the first real multi-GPU run will be read by -- per-rank step times, the exposed wait for the side-stream
+    # gather, how the graph was captured, and the cross-rank checksum of the gathered detections
+    assert 0 < line["rank_ms_per_step"]["min"] <= line["rank_ms_per_step"]["max"] == line["ms_per_step"]
+    assert line["graph_capture"] == "2-stream" and line["gather"]["check"].startswith("ok: 2 ranks")
+    assert line["gather"]["exposed_wait_ms_per_step"]["max_over_ranks"] >= 0.0
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two MI355X for an RCCL world of 2")

@@ -543,7 +543,7 @@ def test_model_shares_constants_and_schedules_between_shapes():
     assert len(m._sched_cache) == (n_sched if same else n_sched + 1) and len(m._const_cache) == n_const
     assert all(torch.equal(a, b) for a, b in zip(o1, o1b))
     u1 = {id(t) for _, _, _, l in e1.launches for t in l.tensors if t is not None}
-    assert sum(id(t) in u1 for _, _, _, l in e2.launches for t in l.tensors if t is not None) > 50      # the same constant tensors
+    assert sum(id(t) in u1 for _, _, _, l in e2.launches for t in l.tensors if t is not None) > 20      # the same Winograd-domain weight tensors
     ref = engine.Engine("dla_34", m.state_dict(), 1, 160, 128, head_conv=cfg.MODEL.HEAD_CONV, sigmoid_heads=("hm", "hm_hp"))(x2)
     torch.cuda.synchronize()
     assert all(torch.equal(a, b) for a, b in zip(o2, ref))
