@@ -2,7 +2,7 @@
 # A/B of the DCNv2 kernel variants on the bench workload.  usage: tools/gpu_dcn_ab.sh <tag>
 TAG=${1:-ab}; OUT=gpurun_out/$TAG; mkdir -p $OUT
 timeout 300 python -m pytest tests/test_conv_hip.py -m gpu -x -q -k "dcn" > $OUT/pytest_dcn.log 2>&1; tail -3 $OUT/pytest_dcn.log
-for t in ${TILES:-0 3064 3128 4064 4128}; do
+for t in ${TILES:-0 64064 64128 128064}; do
   CP_DCN_TILE=$t timeout 200 python bench.py --no-cpu-baseline > $OUT/bench_dcn$t.json 2> $OUT/bench_dcn$t.err
   python - <<PY
 import json
