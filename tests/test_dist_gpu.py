@@ -70,3 +70,29 @@ dist.barrier(); dist.destroy_process_group()
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", "29517", str(script), ROOT], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_bench_single_gpu_line_contract():
+    """`python bench.py` as the driver runs it at N = 1 (short): ONE JSON line with the contract's keys, the metric / workload of
+    BASELINE.json configs[2], dtype f32, a `roofline` object whose dominant-kernel time fits inside the step and whose fraction is
+    achieved / peak, and -- with --no-cpu-baseline absent -- a `cpu_baseline` that says which thread count it used."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline"):
+        assert k in line, k
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2 and line["dtype"] == "f32" and line["vs_baseline"] is None
+    assert "DLA-34 512" in line["metric"] and "dla_34 512x512 batch=16" in line["config"]["workload"] and line["scaling"] == "weak"
+    assert abs(line["value"] - 16 * 5 / (line["ms_per_step"] * 5e-3)) / line["value"] < 1e-3
+    roof = line["roofline"]
+    assert roof["bound"] == "mfma" and roof["peak"] == 157.3 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
+    dom_ms = sum(v["ms_per_step"] for k, v in roof["kernels"].items() if k.startswith(roof["kernel"]))
+    assert 0 < dom_ms < line["ms_per_step"] and 0.3 < roof["frac"] < 1.0
+    assert line["graph_capture"] == "2-stream" and line["gather"] is None and line["ranks"] == 1

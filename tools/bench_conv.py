@@ -8,6 +8,10 @@ from centerpose_amd import ops
 
 CASES = {  # name: (B, H, W, Cin, Cout, k, stride, pad, kind)
     "c64_128": (16, 128, 128, 64, 64, 3, 1, 1, "conv"),
+    "c32_128": (8, 128, 128, 32, 32, 3, 1, 1, "conv"),          # HRNet-W32 high-resolution branch at its per-GPU batch
+    "c64_64b8": (8, 64, 64, 64, 64, 3, 1, 1, "conv"),
+    "c128_32b8": (8, 32, 32, 128, 128, 3, 1, 1, "conv"),
+    "c256_16b8": (8, 16, 16, 256, 256, 3, 1, 1, "conv"),
     "c128_64": (16, 64, 64, 128, 128, 3, 1, 1, "conv"),
     "c256_32": (16, 32, 32, 256, 256, 3, 1, 1, "conv"),
     "c512_16": (16, 16, 16, 512, 512, 3, 1, 1, "conv"),
