@@ -160,6 +160,13 @@ def roofline(eng, arch, B):
                             "executed_tflops": round(tf(f["exe_flops"], f["ms"]), 1),
                             "compulsory_tbps": round(f["bytes"] / (f["ms"] * 1e-3) / 1e12, 2)}
                         for k, f in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])},
+            # every __global__ template (tile instantiations summed), so that a kernel a review names can be followed from round to
+            # round even when it is no longer the one with the largest share (round 3: dcn_igemm_kernel 0.585 -> 0.63 made
+            # conv3x3_wino_kernel the largest by a few microseconds)
+            "templates": {k: {"ms_per_step": round(g["ms"], 3), "share": round(g["ms"] / all_ms, 4), "launches": g["launches"],
+                              "executed_tflops": round(tf(g["exe_flops"], g["ms"]), 2),
+                              "frac": round(tf(g["exe_flops"], g["ms"]) / PEAK_F32_MFMA_TFLOPS, 4)}
+                          for k, g in sorted(grp.items(), key=lambda kv: -kv[1]["ms"]) if g["exe_flops"] > 0},
             "all_mfma_kernels": {"ms_per_step": round(mm_ms, 3),
                                  "algorithmic_tflops": round(tf(sum(f["flops"] for f in mm), mm_ms), 2),
                                  "executed_tflops": round(tf(sum(f["exe_flops"] for f in mm), mm_ms), 2),
