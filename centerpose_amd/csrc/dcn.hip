@@ -20,6 +20,17 @@
 #define DCN_MAX_TAPS 9
 typedef float dcn_v2 __attribute__((ext_vector_type(2)));
 
+// r = w.x * c00 + w.y * c01 + w.z * c10 + w.w * c11 on two channels (wxy = (w.x, w.y), wzw = (w.z, w.w)): one v_pk_mul_f32 and three
+// v_pk_fma_f32, the scalar weight broadcast through op_sel (low element) / op_sel + op_sel_hi (high element).  Same products, same order
+// of accumulation as the elementwise form (fma(w.w, c11, fma(w.z, c10, fma(w.y, c01, w.x * c00)))).
+__device__ __forceinline__ void dcn_blend(dcn_v2& r, dcn_v2 wxy, dcn_v2 wzw, dcn_v2 c00, dcn_v2 c01, dcn_v2 c10, dcn_v2 c11)
+{
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(r) : "v"(wxy), "v"(c00));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(r) : "v"(wxy), "v"(c01));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(r) : "v"(wzw), "v"(c10));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(r) : "v"(wzw), "v"(c11));
+}
+
 // One k-step = 16 input channels of one tap: 4 lanes (float4 quads) per pixel, 64 pixels per pass.  The gathers (and the
 // weight slice) of k-step s+1 are issued from inside the MFMA block of k-step s.  Variants measured and removed in round 3
 // (two-deep prefetch, full-line 32-channel gathers, 32-channel k-steps): DESIGN.md 7.3.
@@ -70,6 +81,7 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
         const float* omp = a.om + (size_t)(live ? m : 0) * a.omLd;
         const int by = oy * a.sy - a.py, bx = ox * a.sx - a.px, bpix = b * a.H * a.W;
         const float fH = (float)a.H, fW = (float)a.W;
+        const unsigned ld4 = (unsigned)ld >> 2;
         int t = tap0 + __builtin_amdgcn_readfirstlane(tid / BM);           // wave-uniform: BM is a multiple of the wave size
         int ky = t / a.kw, kx = t - ky * a.kw;                             // scalar
         for (; t < tap1; t += TS) {
@@ -91,7 +103,9 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
             const float lft = l_ok ? hw : lw, rgt = dxb ? lw : 0.f;
             const int yl = min(max(h_low, 0), a.H - 1), xl = min(max(w_low, 0), a.W - 1);      // in range even for an invalid sample
             s_w[t * BM + pl] = make_float4(top * lft, top * rgt, bot * lft, bot * rgt);
-            s_code[t * BM + pl] = (bpix + yl * a.W + xl) | ((dxb ? 1 : 0) << 29) | ((dyb ? 1 : 0) << 30);
+            // base = byte offset of the clamped top-left corner in 16-byte units (< 2^28: the launcher checks 32-bit byte offsets): the
+            // multiply by the pixel stride is done HERE, once per record, not once per (tap, k-walk) in the main loop
+            s_code[t * BM + pl] = (int)((unsigned)(bpix + yl * a.W + xl) * ld4) | ((dxb ? 1 : 0) << 29) | ((dyb ? 1 : 0) << 30);
             kx += TS;
             while (kx >= a.kw) { kx -= a.kw; ++ky; }
         }
@@ -124,7 +138,7 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
                 const int pl = tid / QL + s * PPP;
                 const int code = s_code[tap * BM + pl];
                 wq[s] = s_w[tap * BM + pl];
-                o00[s] = (unsigned)(code & 0x1FFFFFFF) * pixb + (unsigned)q * 16u;
+                o00[s] = (((unsigned)code & 0x0FFFFFFFu) << 4) + (unsigned)q * 16u;
                 o01[s] = o00[s] + (((unsigned)code >> 29) & 1u) * pixb;
                 o10[s] = o00[s] + (((unsigned)code >> 30) & 1u) * rowb;
                 o11[s] = o10[s] + (o01[s] - o00[s]);
@@ -146,14 +160,14 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
             const int pl = tid / QL + s * PPP;
             // packed fp32 (v_pk_mul / v_pk_fma, weight broadcast through op_sel): 8 VALU instructions per float4
             // instead of 16 -- every VALU instruction costs ~4 cycles of matrix-pipe time (tools/micro/wino_loop.hip)
+            // the four blend weights sit in two register pairs; op_sel / op_sel_hi broadcast the low or the high element of a pair to
+            // both halves of the packed operation.  Written out because the compiler copies the odd elements into fresh even
+            // registers first (2 v_mov_b32 per k-step in the main loop's 14 VALU instructions).
             const float4 w = wq[s];
-            const dcn_v2 wx = {w.x, w.x}, wy = {w.y, w.y}, wz = {w.z, w.z}, ww = {w.w, w.w};
-            const dcn_v2 lo = __builtin_elementwise_fma(ww, (dcn_v2){c11[s].x, c11[s].y},
-                              __builtin_elementwise_fma(wz, (dcn_v2){c10[s].x, c10[s].y},
-                              __builtin_elementwise_fma(wy, (dcn_v2){c01[s].x, c01[s].y}, wx * (dcn_v2){c00[s].x, c00[s].y})));
-            const dcn_v2 hi = __builtin_elementwise_fma(ww, (dcn_v2){c11[s].z, c11[s].w},
-                              __builtin_elementwise_fma(wz, (dcn_v2){c10[s].z, c10[s].w},
-                              __builtin_elementwise_fma(wy, (dcn_v2){c01[s].z, c01[s].w}, wx * (dcn_v2){c00[s].z, c00[s].w})));
+            const dcn_v2 wxy = {w.x, w.y}, wzw = {w.z, w.w};
+            dcn_v2 lo, hi;
+            dcn_blend(lo, wxy, wzw, (dcn_v2){c00[s].x, c00[s].y}, (dcn_v2){c01[s].x, c01[s].y}, (dcn_v2){c10[s].x, c10[s].y}, (dcn_v2){c11[s].x, c11[s].y});
+            dcn_blend(hi, wxy, wzw, (dcn_v2){c00[s].z, c00[s].w}, (dcn_v2){c01[s].z, c01[s].w}, (dcn_v2){c10[s].z, c10[s].w}, (dcn_v2){c11[s].z, c11[s].w});
             *reinterpret_cast<float4*>(As + pl * IG_LDK + q * 4) = make_float4(lo.x, lo.y, hi.x, hi.y);
         }
     };
