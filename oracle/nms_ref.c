@@ -1,8 +1,12 @@
 /* TEST INFRASTRUCTURE ONLY -- C restatement of the reference soft_nms_39
  * (lib/external/nms.pyx:172-275), the only variant the detector calls
  * (lib/detectors/multi_pose.py:76-77: soft_nms_39(results, Nt=0.5, method=2)).
- * The Cython source does not compile with Cython 3 / numpy 2 (np.int_t, nms.pyx:32), so parity is
- * pinned by hand-worked cases in tests/test_host_logic.py (test_soft_nms_39_*).  "parity unpinned" by reference vectors.
+ * The Cython source does not compile with Cython 3 / numpy 2 (np.int_t, nms.pyx:32).  Pinned since round 3 against vectors
+ * produced by the reference's OWN source: tests/golden/make_golden_nms.py executes the body of soft_nms_39 as Python (the
+ * `cdef` declarations stripped in memory, float32 numpy scalars standing for the C floats) -> tests/golden/soft_nms_39.npz;
+ * tests/test_host_logic.py::test_soft_nms_39_matches_reference_source_golden: box moves, the 0:39-only swap, discards and `keep`
+ * bit for bit, hard / linear scores bit for bit, Gaussian scores to 1 ulp per decay (exp evaluated in another precision).
+ * Plus hand-worked cases (test_soft_nms_39_hand_worked).
  *
  * boxes: [N,56] float32 rows, modified IN PLACE exactly like the reference: the max-score row is
  * swapped into position i (columns 0..38 only, nms.pyx:214-235 -- the 17 keypoint scores 39..55

@@ -264,3 +264,45 @@ def test_reconcile_state_dict_and_load_model(tmp_path, capsys):
     assert "epoch 12" in out and "Skip loading parameter b.bias" in out and "Drop parameter extra." in out and "No param c.weight." in out
     with pytest.raises(NotImplementedError):
         cpm.load_model(Holder(own), path, optimizer=object())
+
+
+def _check_nms_against_golden(fn, golden_dir):
+    sys.path.insert(0, golden_dir)
+    import make_golden_nms
+    gold = np.load(os.path.join(golden_dir, "soft_nms_39.npz"))
+    for name, (boxes, kw) in make_golden_nms.cases().items():
+        work = boxes.copy()
+        keep = fn(work, **kw)
+        exp, exp_keep = gold[name + "__out"], gold[name + "__keep"].tolist()
+        assert keep == exp_keep, name
+        cols = [c for c in range(56) if c != 4]
+        assert np.array_equal(work[:, cols], exp[:, cols]), name            # every move / swap / discard of the reference, bit for bit
+        if kw.get("method", 0) == 2:       # Gaussian weight: exp() evaluated in another precision than the generator's: 1 ulp per
+            assert np.allclose(work[:, 4], exp[:, 4], rtol=5e-6, atol=0.0), name      # decay, a score takes one per overlapping better box
+        else:
+            assert np.array_equal(work[:, 4], exp[:, 4]), name
+
+
+def test_soft_nms_39_matches_reference_source_golden(golden_dir):
+    """soft_nms_39 pinned against vectors produced by the reference's own source (lib/external/nms.pyx:172-275
+    executed as Python by tests/golden/make_golden_nms.py -- the Cython file does not compile here): the product's host C++
+    (csrc/host_nms.cpp) and the oracle's C restatement (oracle/nms_ref.c) reproduce every box move, the 0:39-only swap, the discards
+    and `keep` bit for bit for the hard / linear methods, and the Gaussian-decayed scores to the last bit of exp()."""
+    import __graft_entry__ as g
+    g.build()
+    from centerpose_amd.detector import soft_nms_39
+    from oracle import dcn as odcn
+    _check_nms_against_golden(soft_nms_39, golden_dir)
+    _check_nms_against_golden(odcn.soft_nms_39, golden_dir)
+
+
+@pytest.mark.reference
+def test_soft_nms_39_golden_reproduces_from_reference_source(golden_dir):
+    """The committed soft_nms_39.npz is what the reference source computes today: regenerate it in memory and compare all bytes."""
+    sys.path.insert(0, golden_dir)
+    import make_golden_nms
+    fresh = make_golden_nms.generate()
+    gold = np.load(os.path.join(golden_dir, "soft_nms_39.npz"))
+    assert sorted(fresh) == sorted(gold.files)
+    for k in fresh:
+        assert np.array_equal(fresh[k], gold[k]), k
