@@ -17,9 +17,12 @@ The pixel arithmetic lives in a third-party dependency that is absent here: **op
   = sub-pixel phase in 1/32 px; the four taps are weighted with (32-fx)(32-fy)*32 ... (sum 32768) and the result is
   (sum + 16384) >> 15; taps outside the image read the border value 0.
 
-**parity unpinned against cv2** (cv2 cannot be imported in this container, so no reference vector exists); pinned by
+pre_process: **parity unpinned against cv2** (cv2 cannot be imported in this container, so no reference vector exists); pinned by
 hand-computed cases in tests/test_prepost.py (identity, integer translation, exact 2x down-scale, half-pixel phases).
 ``get_affine_transform`` follows lib/utils/image.py:27-60 (three point pairs; solved here in closed form).
+post_process: pinned since round 3 against tests/golden/post_process.npz, which tests/golden/make_golden_post.py produces by
+executing the reference's own transform_preds / get_affine_transform / affine_transform / multi_pose_post_process source
+(tests/test_prepost.py::test_post_process_matches_reference_source_golden: within 2e-6 of the reference's float32 rows).
 """
 import numpy as np
 

@@ -149,6 +149,41 @@ def test_post_process_hand_computed():
     assert np.allclose(pp.post_process(dets, meta, 2)[0][:4], [25, 10, 75, 60], atol=1e-3)
 
 
+def _post_golden(golden_dir):
+    import sys
+    sys.path.insert(0, golden_dir)
+    import make_golden_post
+    return make_golden_post, np.load(os.path.join(golden_dir, "post_process.npz"))
+
+
+def test_post_process_matches_reference_source_golden(golden_dir):
+    """post_process (second half) pinned against vectors the reference's OWN source produces: transform_preds /
+    get_affine_transform / affine_transform (lib/utils/image.py:19-84) and multi_pose_post_process (lib/utils/post_process.py:8-19)
+    executed unchanged by tests/golden/make_golden_post.py (their modules cannot be imported: IndentationError + cv2), with
+    cv2.getAffineTransform -- the exact three-point solve -- as the one restated call.  The product's host mirror
+    (centerpose_amd/post_process.py, closed-form similarity transform instead of the three-point construction) reproduces the
+    reference's float32 rows exactly; the oracle (per-point loop) within float32 rounding."""
+    from centerpose_amd import post_process as host
+    mg, gold = _post_golden(golden_dir)
+    for name, (d, m, scale) in mg.cases().items():
+        exp = gold[name]
+        out = host.multi_pose_post_process(d.reshape(1, -1, 56).copy(), [m["c"]], [m["s"]], m["out_height"], m["out_width"])
+        rows = np.array(out[0][1], dtype=np.float32).reshape(-1, 56)
+        rows[:, :4] /= scale
+        rows[:, 5:39] /= scale
+        assert np.array_equal(rows, exp), name
+        ora = pp.post_process(d, m, scale)
+        assert np.abs(ora - exp).max() <= 1e-5 * max(1.0, np.abs(exp).max()), name
+        assert np.array_equal(ora[:, 4], exp[:, 4]) and np.array_equal(ora[:, 39:], exp[:, 39:])
+
+
+@pytest.mark.reference
+def test_post_process_golden_reproduces_from_reference_source(golden_dir):
+    mg, gold = _post_golden(golden_dir)
+    fresh = mg.generate()
+    assert sorted(fresh) == sorted(gold.files) and all(np.array_equal(fresh[k], gold[k]) for k in fresh)
+
+
 @pytest.mark.reference
 def test_arch_presets_equal_the_reference_yamls():
     import yaml
@@ -216,6 +251,19 @@ def test_detector_post_process_vs_oracle(scale):
         assert got.shape == ref.shape == (100, 56) and got.dtype == np.float32
         assert np.array_equal(got[:, 4], ref[:, 4]) and np.array_equal(got[:, 39:], ref[:, 39:])
         assert np.abs(got - ref).max() <= 2e-4        # float32 rounding of a double affine (a few ulp at ~1000 px)
+
+
+@pytest.mark.gpu
+def test_detector_post_process_vs_reference_source_golden(golden_dir):
+    """The detector's device post_process (cp_transform_dets_f32) against the rows the reference's own source computes
+    (tests/golden/post_process.npz): scores / joint scores bit-equal, coordinates within float32 rounding of the double affine."""
+    mg, gold = _post_golden(golden_dir)
+    det = _det("res_50", TEST__FLIP_TEST=False)
+    for name, (d, m, scale) in mg.cases().items():
+        got = det.post_process(torch.from_numpy(d).cuda(), m, scale)[1]
+        exp = gold[name]
+        assert got.shape == exp.shape and np.array_equal(got[:, 4], exp[:, 4]) and np.array_equal(got[:, 39:], exp[:, 39:]), name
+        assert np.abs(got - exp).max() <= 2e-4, (name, float(np.abs(got - exp).max()))
 
 
 @pytest.mark.gpu
