@@ -323,11 +323,11 @@ def wino_ksplit(B, H, W, cin, cout):
     return S if blocks < 256 else 1
 
 
-def dcn_ksplit(M, ldw):
+def dcn_ksplit(M, ldw, taps=9):
     """Split-K factor for a DCNv2 launch with M output pixels and ldw (padded) output channels: 3 (three taps per block) when the
     64 x 64 tiling gives fewer than 2 blocks per CU on 256 CUs, else 1.  Measured on MI355X, B = 16: 512 -> 256 @16x16 runs at
     50 TF unsplit (256 blocks x 288 k-steps), 256 -> 64 @32x32 at 48 TF."""
-    if ldw % 64 != 0:
+    if ldw % 64 != 0 or taps < 3:
         return 1
     blocks = -(-M // 64) * (ldw // 64)
     return 3 if blocks < 512 else 1
