@@ -18,6 +18,7 @@ CASES = {  # name: (B, H, W, Cin, Cout, k, stride, pad, kind)
     "head": (16, 128, 128, 64, 1536, 3, 1, 1, "conv"),
     "om64_128": (16, 128, 128, 64, 27, 3, 1, 1, "conv"),
     "om512_16": (16, 16, 16, 512, 27, 3, 1, 1, "conv"),
+    "om128_64": (16, 64, 64, 128, 27, 3, 1, 1, "conv"),
     "om256_32": (16, 32, 32, 256, 27, 3, 1, 1, "conv"),
     "l0": (16, 512, 512, 16, 16, 3, 1, 1, "conv"),
     "l1": (16, 512, 512, 16, 32, 3, 2, 1, "conv"),
