@@ -33,18 +33,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline int cp_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a PER-DEVICE property of a kernel: one guard per (kernel instantiation,
-// device), safe across threads.  `need(bytes)` is true the first time this device asks for at least `bytes`.
-#include <atomic>
+// device).  `ensure(kernel, bytes)` raises the kernel's limit to `bytes` unless this device already has at least that much; the
+// check and the attribute call sit under one mutex (cold path: taken once per instantiation and device in practice), so a second
+// thread can never see the new size before the attribute is in place, and a failed call leaves the guard where it was -- the
+// next launch tries again and reports the same error instead of launching with too much dynamic LDS.
+#include <mutex>
 struct CpLdsGuard {
-    std::atomic<int> have[16] = {};
-    bool need(int bytes) {
+    std::mutex mu;
+    int have[16] = {};
+    hipError_t ensure(const void* kernel, int bytes) {
         int d = 0;
         (void)hipGetDevice(&d);
-        std::atomic<int>& h = have[d & 15];
-        int cur = h.load(std::memory_order_relaxed);
-        while (cur < bytes)
-            if (h.compare_exchange_weak(cur, bytes)) return true;
-        return false;
+        std::lock_guard<std::mutex> lock(mu);
+        if (have[d & 15] >= bytes) return hipSuccess;
+        const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        if (e == hipSuccess) have[d & 15] = bytes;
+        return e;
     }
 };
 

@@ -238,8 +238,8 @@ static int launch_patch(const ConvArgs& a, hipStream_t s)
     auto kern = conv3x3_patch_kernel<BN, WAVES_M, WAVES_N, MF>;
     const int smem = (P3_PATCH + 9 * BN * IG_LDK) * 4;
     static CpLdsGuard guard;
-    if (smem > 64 * 1024 && guard.need(smem)) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (smem > 64 * 1024) {
+        const hipError_t e = guard.ensure((const void*)kern, smem);
         if (e != hipSuccess) { cp_set_error("conv3x3_patch: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
     }
     const int tilesX = cp_cdiv(a.W, P3_TW), tilesY = cp_cdiv(a.H, P3_TH);

@@ -702,11 +702,9 @@ static int launch_wino(const ConvArgs& a, hipStream_t s)
     using Geo = WgGeo<MT, KS>;
     const int smem = Geo::SMEM_FLOATS * 4;
     static CpLdsGuard guard;           // once per (instantiation, device), on the first (warm-up) launch: not legal inside a stream capture
-    if (smem > 64 * 1024 && guard.need(smem)) {
-        if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess) {
-            cp_set_error("conv3x3_winograd: cannot reserve %d B LDS", smem);
-            return 2;
-        }
+    if (smem > 64 * 1024) {
+        const hipError_t e = guard.ensure((const void*)kern, smem);
+        if (e != hipSuccess) { cp_set_error("conv3x3_winograd: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
     }
     WgGrid gd;
     gd.tilesX = cp_cdiv(a.W, WG_TW); gd.tilesY = cp_cdiv(a.H, Geo::TH);
@@ -728,8 +726,8 @@ static int launch_wino_vs64(const ConvArgs& a, hipStream_t s, int ngroups, const
     const int smem = (MM ? WGV_SMEM_FLOATS_MM : WGV_SMEM_FLOATS) * 4;
     static_assert(WGV_SMEM_FLOATS_MM >= WGV_CGS * WGV_CG, "the 64-channel patch must fit the MM layout");
     static CpLdsGuard guard;
-    if (guard.need(smem)) {
-        hipError_t e = hipFuncSetAttribute((const void*)conv3x3_wino_vs64_kernel<N2, MM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    {
+        const hipError_t e = guard.ensure((const void*)conv3x3_wino_vs64_kernel<N2, MM>, smem);
         if (e != hipSuccess) { cp_set_error("conv3x3_winograd: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
     }
     WgGrid gd;

@@ -202,8 +202,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t s)
     const int smem = a.outNCHW ? T::SMEM : T::NHWC_BYTES;
     static CpLdsGuard guard;
     constexpr int smem_max = T::SMEM > T::NHWC_BYTES ? T::SMEM : T::NHWC_BYTES;
-    if (smem > 64 * 1024 && guard.need(smem_max))
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem_max);
+    if (smem > 64 * 1024) {
+        const hipError_t e = guard.ensure((const void*)kern, smem_max);
+        if (e != hipSuccess) { cp_set_error("conv2d: cannot reserve %d B LDS: %s", smem_max, hipGetErrorString(e)); return 2; }
+    }
     const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN) * (a.nsub > 1 ? a.nsub : 1);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
     cp_note_kernel("igemm_conv_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, WAVES_M, WAVES_N, MF, STEM ? "true" : "false");

@@ -228,8 +228,10 @@ static int launch_dcn(const ConvArgs& a, hipStream_t s)
     const int epi = a.outNCHW ? T::EPI_BYTES : T::EPV_BYTES;
     const int smem = epi > main_bytes ? epi : main_bytes;
     static CpLdsGuard guard;
-    if (smem > 64 * 1024 && guard.need(smem))
-        (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (smem > 64 * 1024) {
+        const hipError_t e = guard.ensure((const void*)kern, smem);
+        if (e != hipSuccess) { cp_set_error("dcn_v2: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
+    }
     const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN) * a.ksplit;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
     cp_note_kernel("dcn_igemm_kernel<%d, %d, %d, %d, %d>", BM, BN, WAVES_M, WAVES_N, MF);

@@ -301,9 +301,8 @@ extern "C" int cp_decode_topk_f32(const float* heat, const float* hm_hp, int B, 
     const size_t lds = (size_t)nmax * 4 + 2 * TK_MAX_K * 8 + 256 * 4 + TK_WAVES * 4 + 16;
     static CpLdsGuard lds_reserved[2];        // per (instantiation, device)
     const int ck = nchunks > 1;
-    if (lds_reserved[ck].need((int)lds)) {
-        hipError_t e = hipFuncSetAttribute(ck ? (const void*)nms_topk_kernel<true> : (const void*)nms_topk_kernel<false>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    {
+        const hipError_t e = lds_reserved[ck].ensure(ck ? (const void*)nms_topk_kernel<true> : (const void*)nms_topk_kernel<false>, (int)lds);
         if (e != hipSuccess) { cp_set_error("decode: cannot reserve %zu B LDS: %s", lds, hipGetErrorString(e)); return 2; }
     }
     hipStream_t s = (hipStream_t)stream;

@@ -120,8 +120,8 @@ static int launch_stem(const float* x, const float* w, const float* scale, const
     const int smem = (((3 * PH * PW + 3) & ~3) + S7_STEPS * NOUT * IG_LDK) * 4;
     auto kern = stem7x7_kernel<NOUT, S, TH, TW>;
     static CpLdsGuard guard;
-    if (smem > 64 * 1024 && guard.need(smem)) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (smem > 64 * 1024) {
+        const hipError_t e = guard.ensure((const void*)kern, smem);
         if (e != hipSuccess) { cp_set_error("stem7x7: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
     }
     const int tilesX = cp_cdiv(Wo, TW), tilesY = cp_cdiv(Ho, TH);

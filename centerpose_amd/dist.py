@@ -77,7 +77,7 @@ class DetsGatherer:
     outstanding gather and returns its [B_global, K, D] tensor.  One step of pipelining; world 1 is a pass-through.
     `submit` must be given a tensor the producer will NOT overwrite before `collect` (the exchange reads it asynchronously):
     `MultiPoseDetector.process` / `BackBoneWithHead.process` return such a private copy; a raw `Engine.dets` buffer must be
-    cloned first (bench.py does).  `last_wait_ms()` reports how long the last `collect` left the compute stream waiting."""
+    cloned first (bench.py does).  `exposed_wait_ms()` reports how long the `collect` calls left the compute stream waiting (total, worst)."""
 
     def __init__(self, global_batch=None, time_waits=False):
         self.global_batch = global_batch

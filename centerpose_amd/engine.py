@@ -400,6 +400,17 @@ def list_schedule(deps, durations, nstreams=2):
     return order, assign, (max(finish) if n else 0.0)
 
 
+def order_is_topological(deps, order):
+    """True iff `order` is a permutation of range(len(deps)) in which every launch comes after all of deps[launch]."""
+    n = len(deps)
+    if len(order) != n or sorted(order) != list(range(n)):
+        return False
+    pos = [0] * n
+    for p, i in enumerate(order):
+        pos[i] = p
+    return all(pos[j] < pos[i] for i, d in enumerate(deps) for j in d)
+
+
 class Engine:
     """Static-shape inference engine for one (arch, batch, H, W)."""
 
@@ -424,6 +435,7 @@ class Engine:
             pb = PlanBuilder(sd, batch, self.device, sigmoid_heads, const_cache)
             pb.network(self.arch, Act(height, width, 3, self.input), head_conv)
         self.launches = pb.launches
+        self.emission = pb.launches    # the list in the order of the reference's forward(); `launches` may later be re-ordered by the schedule
         self.outputs = pb.outputs
         self.flops_per_image = pb.flops
         self.activation_bytes = pb.bytes_alloc
@@ -447,8 +459,7 @@ class Engine:
             ws = torch.zeros((2, B, 1 + J, K), dtype=torch.float32, device=self.device)
             self.dets = torch.zeros((B, K, 5 + 3 * J), dtype=torch.float32, device=self.device)
         topk, assign = ops.decode_launches(hm, wh, hps, reg, hm_hp, hp_offset, K, ws, self.dets)
-        self.launches.append(("decode", "decode.nms_topk", 0, topk))
-        self.launches.append(("decode", "decode.pose_assign", 0, assign))
+        self.launches = self.emission = self.launches + [("decode", "decode.nms_topk", 0, topk), ("decode", "decode.pose_assign", 0, assign)]
         self.activation_bytes += 4 * (ws.numel() + self.dets.numel())
         self.decode_k = K
 
@@ -478,12 +489,13 @@ class Engine:
         for _, _, _, launch in self.launches:
             launch.run()
 
-    def dependencies(self):
-        """Data dependencies of the launch schedule: for every launch the indices of earlier launches it must follow
-        (RAW on its inputs, WAW / WAR on its output), per storage -- buffer reuse shows up here as WAR edges."""
+    def dependencies(self, launches=None):
+        """Data dependencies of the launch schedule (`launches`: another order of the same records, default the current one):
+        for every launch the indices of earlier launches it must follow (RAW on its inputs, WAW / WAR on its output), per
+        storage -- buffer reuse shows up here as WAR edges."""
         deps = []
         last_writer, readers = {}, {}
-        for i, (_, _, _, launch) in enumerate(self.launches):
+        for i, (_, _, _, launch) in enumerate(self.launches if launches is None else launches):
             rd = {t.untyped_storage().data_ptr() for t in launch.reads}
             wr = {launch.out.untyped_storage().data_ptr()}
             d = set()
@@ -517,15 +529,20 @@ class Engine:
         self.stream_plan = [assign[i] for i in order]
         return makespan
 
-    def plan_schedule(self, durations=None, nstreams=2):
+    def plan_schedule(self, durations=None, nstreams=2, launches=None):
         """The schedule `schedule()` would apply, WITHOUT touching the engine: (order, stream of launch i, simulated makespan).
         durations: per-launch times; None = measured now (`profile_in_sequence`); "model" = a deterministic roofline estimate
-        (max(flops / 100 TFLOP/s, bytes / 4 TB/s) + 5 us), for plan files that must be byte-identical from run to run."""
+        (max(flops / 100 TFLOP/s, bytes / 4 TB/s) + 5 us), for plan files that must be byte-identical from run to run.
+        launches: schedule this order of the records instead of the current one (`self.emission` for a result that does not
+        depend on an earlier, measured re-ordering; only with durations="model")."""
         if durations is None:
+            if launches is not None:
+                raise ValueError("measured durations belong to the engine's current launch order")
             durations = [r["ms"] for r in self.profile_in_sequence(iters=3)]
         elif isinstance(durations, str) and durations == "model":
-            durations = [max(f / 100e12, nb / 4e12) * 1e3 + 5e-3 for (_, _, f, _), nb in zip(self.launches, self.launch_bytes())]
-        return list_schedule(self.dependencies(), durations, nstreams)
+            ll = self.launches if launches is None else launches
+            durations = [max(f / 100e12, nb / 4e12) * 1e3 + 5e-3 for (_, _, f, _), nb in zip(ll, self.launch_bytes(ll))]
+        return list_schedule(self.dependencies(launches), durations, nstreams)
 
     def _run_branches(self, main, nstreams, deps, assign=None):
         """Enqueue the schedule on `nstreams` streams (main + side streams): independent branches of the graph
@@ -600,8 +617,15 @@ class Engine:
             if getattr(self, "stream_plan", None) is None and nstreams == 2 and os.environ.get("CP_SCHED", "1") != "0":
                 # the measured critical-path schedule costs three eager passes: a model that compiles a plan per image size
                 # (FIX_RES = false) reuses the order / stream placement of an earlier plan with the same launch list
-                names = tuple(n for _, n, _, _ in self.launches)
-                hit = self.sched_cache.get(names) if self.sched_cache is not None else None
+                # A cached (order, streams) is valid only for the dependency DAG it was computed on, and that DAG includes the
+                # WAR / WAW edges of BufferPool reuse, which depend on buffer SIZES (split-K / split-C workspaces change with the
+                # batch and the map size while the launch names stay the same: ADVICE r3).  The key therefore carries the DAG of
+                # the emission order, and a hit is still checked to be a topological order of it before it is applied.
+                deps0 = self.dependencies()
+                key = (tuple(n for _, n, _, _ in self.launches), tuple(tuple(d) for d in deps0))
+                hit = self.sched_cache.get(key) if self.sched_cache is not None else None
+                if hit is not None and not order_is_topological(deps0, hit[0]):
+                    hit = None
                 if hit is not None:
                     self.launches = [self.launches[i] for i in hit[0]]
                     self.stream_plan = list(hit[1])
@@ -610,7 +634,7 @@ class Engine:
                     self.launches = [self.launches[i] for i in order]
                     self.stream_plan = [assign[i] for i in order]
                     if self.sched_cache is not None:
-                        self.sched_cache[names] = (order, list(self.stream_plan))
+                        self.sched_cache[key] = (order, list(self.stream_plan))
             deps = self.dependencies()
             try:
                 g = torch.cuda.CUDAGraph()
@@ -651,10 +675,11 @@ class Engine:
 
     __call__ = forward
 
-    def launch_bytes(self):
+    def launch_bytes(self, launches=None):
         """Algorithmic (compulsory) HBM bytes of every launch: each tensor argument once -- inputs, residual, the weights
         the kernel actually reads (Winograd launches carry U, not the direct weights), output."""
-        return [sum(4 * t.numel() for t in launch.tensors if t is not None) for _, _, _, launch in self.launches]
+        return [sum(4 * t.numel() for t in launch.tensors if t is not None)
+                for _, _, _, launch in (self.launches if launches is None else launches)]
 
     def profile(self, iters=5):
         """Per-launch timing, every launch repeated `iters` times back to back (cache-hot: an optimistic number,

@@ -11,7 +11,9 @@ they name -- in a flat little-endian binary layout with no pickled objects, so t
 
 Layout (all integers little-endian; offsets in bytes from the start of the file):
 
-    char[8]  magic "CPPLAN04"  ("CPPLAN03" files are still read: no checksum; "CPPLAN02": also stream = 0 in every op)
+    char[8]  magic "CPPLAN04"  (the parser still knows the "CPPLAN03" / "CPPLAN02" framing -- no checksum / no stream field -- but
+                            their descriptor blobs have an older ABI's size, so `load_plan` / `cp_plan_load` reject such files:
+                            re-export them with `Engine.save_plan`)
     u32      abi            cp_abi_version() of the library that wrote it (descriptor struct layouts)
     u32      B, H, W        network input [B,3,H,W]
     u32      nbuf, nconst, nops, nout
@@ -152,12 +154,23 @@ def save_plan(engine, path, deterministic=False):
     engine captured with CP_STREAMS=1 / CP_SCHED=0 keeps its launch order, `stream_of_launch` and profile indices: ADVICE r2)."""
     import os
     launches, streams = engine.launches, getattr(engine, "stream_plan", None)
-    if (streams is None or deterministic) and os.environ.get("CP_SCHED", "1") != "0" and os.environ.get("CP_STREAMS", "2") == "2":
-        if engine.graph is None and not deterministic:
+    can_schedule = os.environ.get("CP_SCHED", "1") != "0" and os.environ.get("CP_STREAMS", "2") == "2"
+    if deterministic:
+        # Scheduled from the EMISSION order (the reference's forward() order, kept on the engine) with model durations: neither
+        # an earlier measured re-ordering of `engine.launches` nor measured times can leak into the bytes (ADVICE r3).
+        if not can_schedule:
+            raise ValueError("save_plan(deterministic=True) writes the two-stream model schedule: unset CP_SCHED=0 / CP_STREAMS")
+        base = getattr(engine, "emission", None)
+        if base is None:
+            raise ValueError("save_plan(deterministic=True): this engine was loaded from a plan file and has no emission order")
+        order, assign, _ = engine.plan_schedule("model", launches=base)
+        launches, streams = [base[i] for i in order], [assign[i] for i in order]
+    elif streams is None and can_schedule:
+        if engine.graph is None:
             engine.schedule()
             launches, streams = engine.launches, engine.stream_plan
         else:
-            order, assign, _ = engine.plan_schedule("model" if deterministic else None)
+            order, assign, _ = engine.plan_schedule(None)
             launches, streams = [engine.launches[i] for i in order], [assign[i] for i in order]
     meta = {"arch": engine.arch, "flops_per_image": int(engine.flops_per_image)}
     blob = serialize(launches, meta, engine.input, engine.outputs, int(_lib.lib().cp_abi_version()), streams)

@@ -254,17 +254,37 @@ def _dcn_case(seed, B, C, Co, H, W, big_offsets):
     return x, w, b, off, m
 
 
+def _dcn_mask_logits(seed, shape):
+    """Mask LOGITS for the om_sigmoid=True mode -- the mode every in-plan launch runs (engine.emit_dcn; the reference applies
+    torch.sigmoid to the mask third of conv_offset_mask's output, DCNv2/dcn_v2.py:117-127, then calls dcn_v2_forward): normal
+    logits plus saturating ones (|logit| > 20, +-90: exp overflows / underflows in float32).  -> (logits, sigmoid(logits)) with
+    the sigmoid evaluated by torch in float32 like the reference."""
+    r = np.random.RandomState(seed + 1000)
+    lg = (r.randn(*shape) * 3.0).astype(np.float32)
+    flat = lg.reshape(-1)
+    flat[0::17] = 25.0
+    flat[1::19] = -25.0
+    flat[2::23] = 90.0
+    flat[3::29] = -90.0
+    flat[4::31] = 0.0
+    return lg, torch.sigmoid(torch.from_numpy(lg)).numpy()
+
+
 def test_dcn_v2_split_k_vs_scalar_oracle():
     """cp_dcn_desc.ksplit: split-K over the taps into raw partial sums + cp_splitk_reduce_f32 (fixed-order sum, bias, ReLU) ==
     the scalar oracle; S = 3 and the extreme S = 9 (one tap per block), ragged M, 64- and 128-wide N tiles; twice -> same bits."""
     from centerpose_amd import ops
     from oracle import dcn as odcn
-    for (C, Co, H, W, S, tile) in [(64, 64, 9, 7, 3, 0), (32, 128, 6, 10, 9, 64128), (128, 256, 8, 8, 3, 64064), (48, 64, 5, 9, 2, 0)]:
+    cases = [(64, 64, 9, 7, 3, 0), (32, 128, 6, 10, 9, 64128), (128, 256, 8, 8, 3, 64064), (48, 64, 5, 9, 2, 0)]
+    for (C, Co, H, W, S, tile), sig in [(c, g) for c in cases for g in (False, True)]:
         x, w, b, off, m = _dcn_case(C + S, 2, C, Co, H, W, True)
+        m_in = m
+        if sig:              # the timed mode: mask logits in `om`, sigmoid inside the kernel (VERDICT r3 #2)
+            m_in, m = _dcn_mask_logits(C + S, m.shape)
         ref = np.maximum(odcn.dcn_v2_forward_c(x, w, b, off, m), 0.0)
         om = torch.zeros(2, H, W, 32)
         om[..., :18] = torch.from_numpy(off).permute(0, 2, 3, 1)
-        om[..., 18:27] = torch.from_numpy(m).permute(0, 2, 3, 1)
+        om[..., 18:27] = torch.from_numpy(m_in).permute(0, 2, 3, 1)
         wp = ops.pack_conv_weight(torch.from_numpy(w).cuda())
         ldw = wp.shape[0]
         sc, sh = ops.fold_bn(Co, None, torch.from_numpy(b).cuda())
@@ -272,7 +292,7 @@ def test_dcn_v2_split_k_vs_scalar_oracle():
         out = torch.full((2, H, W, Co + 4), float("nan"), device="cuda")
         xs, oms = _nhwc(torch.from_numpy(x)), om.cuda()
         la = ops.dcn_v2_launch(xs, oms, wp, torch.ones(ldw, device="cuda"), torch.zeros(ldw, device="cuda"), ws, cout=ldw,
-                               om_sigmoid=False, tile=tile, ksplit=S)
+                               om_sigmoid=sig, tile=tile, ksplit=S)
         lb = ops.splitk_reduce_launch(ws, sc, sh, out[..., :Co], cout=Co, act=ops.ACT_RELU)
         la.run(); lb.run()
         first = out.clone()
@@ -289,18 +309,24 @@ def test_dcn_v2_split_k_vs_scalar_oracle():
                                                (128, 256, 8, 8, False, 64128), (32, 64, 12, 12, True, 128064),
                                                (96, 128, 6, 10, True, 64032), (48, 64, 5, 9, True, 64032),
                                                (128, 64, 11, 13, True, 0), (256, 64, 5, 6, True, 0)])
-def test_dcn_v2_vs_scalar_oracle(C, Co, H, W, big, tile):
+@pytest.mark.parametrize("sig", [False, True], ids=["mask", "logits"])
+def test_dcn_v2_vs_scalar_oracle(C, Co, H, W, big, tile, sig):
+    """sig=True is the mode of every in-plan launch (the timed path): `om` carries mask LOGITS and the kernel applies the sigmoid
+    (v_rcp_f32(1 + exp(-x))); reference = torch.sigmoid in float32 -> the scalar oracle, at the same 1e-4 (SURVEY 8d gate 2)."""
     from centerpose_amd import ops
     from oracle import dcn as odcn
     x, w, b, off, m = _dcn_case(C + H, 2, C, Co, H, W, big)
+    m_in = m
+    if sig:
+        m_in, m = _dcn_mask_logits(C + H, m.shape)
     ref = odcn.dcn_v2_forward_c(x, w, b, off, m)
     om = torch.zeros(2, H, W, 32)
     om[..., :18] = torch.from_numpy(off).permute(0, 2, 3, 1)
-    om[..., 18:27] = torch.from_numpy(m).permute(0, 2, 3, 1)
+    om[..., 18:27] = torch.from_numpy(m_in).permute(0, 2, 3, 1)
     sc, sh = ops.fold_bn(Co, None, torch.from_numpy(b).cuda())
     out = torch.empty(2, H, W, Co, device="cuda")
     ops.dcn_v2(_nhwc(torch.from_numpy(x)), om.cuda(), ops.pack_conv_weight(torch.from_numpy(w).cuda()), sc, sh, out,
-               cout=Co, om_sigmoid=False, tile=tile)
+               cout=Co, om_sigmoid=sig, tile=tile)
     _close(out.permute(0, 3, 1, 2), torch.from_numpy(ref), 1e-4)
 
 

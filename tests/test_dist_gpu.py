@@ -96,3 +96,8 @@ def test_bench_single_gpu_line_contract():
     dom_ms = sum(v["ms_per_step"] for k, v in roof["kernels"].items() if k.startswith(roof["kernel"]))
     assert 0 < dom_ms < line["ms_per_step"] and 0.3 < roof["frac"] < 1.0
     assert line["graph_capture"] == "2-stream" and line["gather"] is None and line["ranks"] == 1
+    # configs[1] and the per-GPU shape of configs[4] ride behind the timed region as `other_configs`
+    for k in ("res_50_b8", "hrnet_b8"):
+        oc = line["other_configs"][k]
+        assert "error" not in oc, oc
+        assert oc["images_per_sec"] > 0 and oc["graph_capture"] == "2-stream" and 0.2 < oc["all_mfma_executed_frac"] < 1.0

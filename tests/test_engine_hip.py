@@ -93,7 +93,10 @@ def test_process_end_to_end(arch):
           "within 2e-2: %.4f" % (arch, int(stable.sum()), stable.size, stable.mean(),
                                  np.abs(dets[..., 4][stable] - ref[..., 4][stable]).max(),
                                  np.abs(dets[..., :4][stable] - ref[..., :4][stable]).max(), close.mean()))
-    assert stable.mean() > 0.5, "only %.3f of the detections have a score gap > 2e-4" % stable.mean()
+    # the stable fraction is a property of the ORACLE's scores (seeded checkpoint + images): 0.965 for dla_34, 0.870 for res_50.
+    # Floor = that minus a margin: a change that leaves only half of the detections compared must fail.
+    floor = {"dla_34": 0.93, "res_50": 0.83}[arch]
+    assert stable.mean() > floor, "only %.3f of the detections have a score gap > 2e-4 (expected > %.2f)" % (stable.mean(), floor)
     assert np.allclose(dets[..., 4][stable], ref[..., 4][stable], atol=1e-3)
     assert np.allclose(dets[..., :4][stable], ref[..., :4][stable], atol=2e-2)
     # keypoint coordinates: allow rare accept/reject flips at a threshold
@@ -158,6 +161,31 @@ def test_plan_roundtrip(arch, tmp_path):
         torch.cuda.synchronize()
         assert len(out) == 6 and all(torch.equal(p, q) for p, q in zip(ref, out))
         assert len(e2.profile(iters=1)) == len(e2.launches)
+
+
+def test_deterministic_plan_same_bytes_before_and_after_capture(tmp_path, monkeypatch):
+    """save_plan(deterministic=True): scheduled from the engine's EMISSION order with model durations, so the bytes do
+    not depend on whether -- and in which measured order -- the engine has captured its graph; two engines of the same checkpoint
+    write the same file; the flag raises when it cannot be honoured (CP_SCHED=0); the plan still runs to the engine's bits."""
+    from centerpose_amd import engine, synth
+    sd = synth.make_state_dict("dla_34")
+    x = synth.make_images(2, 128, 128).cuda()
+    eng = engine.Engine("dla_34", sd, 2, 128, 128, use_graph=True)
+    pa, pb, pc = (str(tmp_path / n) for n in ("a.cpplan", "b.cpplan", "c.cpplan"))
+    eng.save_plan(pa, deterministic=True)                      # before capture
+    ref = [t.clone() for t in eng(x)]                          # captures: measured critical-path order
+    torch.cuda.synchronize()
+    assert eng.graph is not None and eng.launches is not eng.emission
+    eng.save_plan(pb, deterministic=True)                      # after capture
+    engine.Engine("dla_34", sd, 2, 128, 128, use_graph=False).save_plan(pc, deterministic=True)
+    a, b, c = (open(q, "rb").read() for q in (pa, pb, pc))
+    assert a == b and a == c
+    out = engine.Engine.from_plan(pb, use_graph=False)(x)
+    torch.cuda.synchronize()
+    assert all(torch.equal(p, q) for p, q in zip(ref, out))
+    monkeypatch.setenv("CP_SCHED", "0")
+    with pytest.raises(ValueError):
+        eng.save_plan(pa, deterministic=True)
 
 
 C_PLAN_CHILD = r"""
@@ -478,8 +506,10 @@ def test_timed_configuration_parity(arch, B):
     tile choices of this size.  Reference side: MultiPoseDetector.process, lib/detectors/multi_pose.py:29-60.
     (a) images 0, B/2-1, B-1 against the CPU oracle network: the north-star 1e-3 bar on every head;
     (b) dets of ALL images bit-equal to the oracle decode of the engine's own head maps;
-    (c) dla_34 B=16: the kernel instantiations this engine dispatched to are exactly the ones in the committed bench line
-        (profiles/bench_line.json -> roofline.kernels), i.e. the tested kernels ARE the timed kernels;
+    (c) the kernel instantiations this engine dispatched to are WRITTEN to gpurun_out/tested_kernels_<arch>.json;
+        tools/gpu_check.sh compares that list with `roofline.kernels` of the bench line of the same box session (the tested kernels
+        ARE the timed kernels).  Round 3 asserted against the committed profiles/bench_line.json here, which made the driver's test
+        run depend on a hand-refreshed file: a stale file now only prints a note;
     (d) a second replay reproduces every bit."""
     import json
     import sys
@@ -513,10 +543,18 @@ def test_timed_configuration_parity(arch, B):
     print("%s B=%d: worst error / tolerance per head: %s" % (arch, B, {k: round(v, 4) for k, v in worst.items()}))
     kernels = sorted({l.kernel or l.fn for _, _, _, l in eng.launches})
     print("kernel instantiations:", kernels)
-    if arch == "dla_34":                                                                   # (c)
-        assert os.path.exists(BENCH_LINE), "profiles/bench_line.json (the committed `python bench.py` line) is missing"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))                      # (c)
+    try:
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "tested_kernels_%s.json" % arch), "w") as f:
+            json.dump({"arch": arch, "batch": B, "kernels": kernels}, f, indent=1)
+    except OSError as e:
+        print("could not write the tested-kernel list:", e)
+    if arch == "dla_34" and os.path.exists(BENCH_LINE):
         timed = sorted(json.load(open(BENCH_LINE))["roofline"]["kernels"])
-        assert kernels == timed, "tested kernels %s != timed kernels %s -- refresh profiles/bench_line.json" % (kernels, timed)
+        if kernels != timed:
+            print("note: profiles/bench_line.json lists other kernels than this engine dispatched to (stale file?):",
+                  sorted(set(kernels) ^ set(timed)))
 
 
 def test_model_shares_constants_and_schedules_between_shapes():
@@ -534,7 +572,9 @@ def test_model_shares_constants_and_schedules_between_shapes():
     o2 = [t.clone() for t in m(x2)]
     e2 = m._engines[(1, 160, 128)]
     assert len(m._const_cache) == n_const                     # nothing was uploaded or transformed again
-    same = sorted(n for _, n, _, _ in e1.launches) == sorted(n for _, n, _, _ in e2.launches)     # (split factors may differ by shape)
+    # a schedule is shared only between plans with the same launch list AND the same dependency DAG (buffer reuse depends on sizes)
+    same = [n for _, n, _, _ in e1.emission] == [n for _, n, _, _ in e2.emission] and \
+        e1.dependencies(e1.emission) == e2.dependencies(e2.emission)
     assert len(m._sched_cache) == (n_sched if same else n_sched + 1)
     if same:
         assert e2.stream_plan == e1.stream_plan and [n for _, n, _, _ in e1.launches] == [n for _, n, _, _ in e2.launches]
@@ -553,3 +593,33 @@ def test_model_shares_constants_and_schedules_between_shapes():
     o3 = m(x1)
     torch.cuda.synchronize()
     assert not torch.equal(o3[0], o1[0])
+
+
+def test_schedule_cache_never_applies_an_order_of_another_dag():
+    """plans of one model with the SAME launch names can have DIFFERENT dependency DAGs -- BufferPool reuse adds
+    WAR / WAW edges that depend on buffer sizes, and the split-K / split-C workspaces change size with batch and map size.  A cached
+    (order, streams) of one DAG applied to the other ran `conv_offset_mask` before the launches whose workspace it aliases.  The cache
+    key now carries the DAG and a hit is validated as a topological order of the emission-order DAG.  Shapes from the advisor's
+    simulation: (1, 512, 512) then (8, 64, 64) and (8, 128, 96); every plan == a stand-alone engine of that shape, bit for bit."""
+    from centerpose_amd import config, engine, model, synth
+    cfg = config.get_cfg("dla_34", TEST__FLIP_TEST=False)
+    m = model.create_model(cfg.MODEL.NAME, cfg.MODEL.HEAD_CONV, cfg).to("cuda")
+    seen = []
+    for (B, H, W) in [(1, 512, 512), (8, 64, 64), (8, 128, 96), (8, 64, 64)]:
+        x = synth.make_images(B, H, W, seed=H + W).cuda()
+        got = [t.clone() for t in m(x)]
+        eng = m._engines[(B, H, W)]
+        deps0 = eng.dependencies(eng.emission)
+        pos = {id(l): i for i, (_, _, _, l) in enumerate(eng.launches)}
+        assert engine.order_is_topological(deps0, sorted(range(len(eng.emission)), key=lambda i: pos[id(eng.emission[i][3])]))
+        seen.append(([n for _, n, _, _ in eng.emission], deps0))
+        ref = engine.Engine("dla_34", m.state_dict(), B, H, W, head_conv=cfg.MODEL.HEAD_CONV, sigmoid_heads=("hm", "hm_hp"))(x)
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(got, ref)), (B, H, W)
+    distinct = []
+    for names, deps in seen:
+        if not any(names == n and deps == d for n, d in distinct):
+            distinct.append((names, deps))
+    assert len(m._sched_cache) == len(distinct)
+    print("shapes with equal names but different DAGs:",
+          sum(1 for i, (n, d) in enumerate(seen) for (n2, d2) in seen[:i] if n == n2 and d != d2))

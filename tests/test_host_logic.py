@@ -306,3 +306,20 @@ def test_soft_nms_39_golden_reproduces_from_reference_source(golden_dir):
     assert sorted(fresh) == sorted(gold.files)
     for k in fresh:
         assert np.array_equal(fresh[k], gold[k]), k
+
+
+def test_order_is_topological_and_list_schedule():
+    """engine.order_is_topological: the check that guards a schedule-cache hit.  list_schedule always returns a
+    topological order of the DAG it was given; the same order is rejected for a DAG with one more (WAR-like) edge against it."""
+    from centerpose_amd.engine import list_schedule, order_is_topological
+    deps = [[], [0], [0], [1], [2], [3, 4]]
+    order, assign, span = list_schedule(deps, [1.0, 2.0, 1.0, 1.0, 3.0, 1.0], 2)
+    assert order_is_topological(deps, order) and sorted(order) == list(range(6)) and set(assign) <= {0, 1}
+    assert order_is_topological(deps, list(range(6)))
+    assert not order_is_topological(deps, [1, 0, 2, 3, 4, 5])          # child before parent
+    assert not order_is_topological(deps, [0, 1, 2, 3, 4])             # not a permutation
+    assert not order_is_topological(deps, [0, 1, 2, 3, 4, 4])
+    # same names, one more edge (buffer reuse): launch 2 must now follow launch 3 -- an order that runs 2 before 3 is refused
+    deps2 = [[], [0], [0, 3], [1], [2], [3, 4]]
+    bad = [0, 2, 1, 3, 4, 5]
+    assert order_is_topological(deps, bad) and not order_is_topological(deps2, bad)
