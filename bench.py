@@ -207,7 +207,8 @@ def roofline(eng, arch, B):
         f = fam.setdefault(r["kernel"] or r["fn"], {"ms": 0.0, "flops": 0.0, "exe_flops": 0.0, "bytes": 0, "launches": 0})
         f["ms"] += r["ms"]
         f["flops"] += r["flops"]
-        f["exe_flops"] += r["flops"] * (16.0 / 36.0 if r["kind"] == "wino" else 1.0)    # F(2x2,3x3): 16 of 36 multiplies
+        # multiplies the matrix cores execute: F(2x2,3x3) 16 of the direct form's 36 per 2x2 tile, F(2x4,3x3) 24 of 72 per 2x4 tile
+        f["exe_flops"] += r["flops"] * {"wino": 16.0 / 36.0, "wino24": 24.0 / 72.0}.get(r["kind"], 1.0)
         f["bytes"] += r["bytes"]
         f["launches"] += 1
     all_ms = sum(f["ms"] for f in fam.values())

@@ -774,6 +774,7 @@ int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant)
                     (((size_t)a.src[0] | (size_t)a.w) & 15) == 0 &&            // 16-byte vector loads of the patch and of U
                     (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
     if (!ok) return -1;
+    if (variant == 24) return cp_launch_conv3x3_wino24(a, s);      // F(2x4,3x3): `a.w` is cp_winograd24_pack_f32's layout
     const int ntiles = (a.Cout + 31) / 32;
     // variant = MT*10 + NT (tuning / tests); 0 = auto.  Measured on MI355X (tools/bench_conv.py, B = 16): the 8x16-pixel x
     // 64-channel block (NT = 2: every V fragment feeds two MFMAs) is the best general shape on every DLA-34 / ResNet-50

@@ -1,0 +1,377 @@
+// 3x3 / stride 1 / pad 1 convolution as a fused Winograd F(2x4,3x3) on the fp32 matrix cores (gfx950).
+//
+// conv3x3_wino.hip computes 2x2 output tiles with 16 multiplies per (cin,cout) -- 4 per output; this variant computes 2x4
+// output tiles from 4x6 input tiles with 24 multiplies -- 3 per output, i.e. 0.75x the MFMAs ("measure one
+// wider Winograd, don't estimate it").  Rows use the F(2,3) transform, columns the F(4,3) transform (Lavin & Gray):
+//     Y = A2^T [ sum_c (G2 g G4^T) .* (B2^T d B4) ] A4
+//     B4^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//     G4   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//     A4^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// Same organisation as the F(2x2) kernel:
+//   * block = 16 x 16 output pixels = 8 x 4 Winograd tiles (one 32-wide MFMA tile) x 32 output channels, 4 waves;
+//   * wave xi owns transform ROW xi (frequencies (xi, nu = 0..5)): row xi of B2^T has two non-zeros, so a lane (tile m, k-half h)
+//     reads two rows x six columns of its 4x6 input tile = 12 ds_read_b128 per 8-channel chunk, forms the row combination with 12
+//     packed fmas and the six column frequencies with 24 packed ops, straight into the MFMA operand registers;
+//   * the raw (16+2) x (16+2) halo patch is staged 16 channels at a time (double buffered, one barrier per stage); layout
+//     [cg][py][px ^ s(py)][4] with s(py) = (py >> 1) & 3 on the low two bits of px and a row pitch of 20 float4: the 16 lanes of a
+//     ds_read_b128 group (4 tile columns x 4 tile rows) hit slot 4 * ((2 tyy + txx) & 3) + (j ^ tyy) mod 16 -- all distinct;
+//   * U = G2 g G4^T (cp_winograd24_pack_f32, fp64, rounded once) streams global -> registers in fragment order
+//     [xi][ntile][kc][nu 6][lane][4], one 8-channel chunk ahead, issued from inside the MFMA block;
+//   * per chunk and wave: 12 ds_read_b128 + 36 packed VALU + 6 global loads feed 24 v_mfma_f32_32x32x2f32;
+//   * epilogue: the nu -> 4 output columns transform (A4) in registers, the xi-sum (A2) across the four waves through LDS, two
+//     output columns per pass (the F(2x2) kernel's reduction buffer, twice), then scale / shift + residual + activation.
+// fp32 throughout.  F(4,3) has larger transform constants than F(2,3): the measured error against an fp64 convolution is in
+// tools/wino_check.py / DESIGN.md 7.1.
+#include "igemm.h"
+
+#define W24_PH 18
+#define W24_PW 18
+#define W24_PWP 20                                 // patch row pitch in float4 slots
+#define W24_KS 16
+#define W24_CGS (W24_KS / 4)
+#define W24_CG (W24_PH * W24_PWP * 4)              // floats per 4-channel plane
+#define W24_STAGE (W24_CGS * W24_CG)               // floats per stage buffer (23 KB)
+#define W24_F4 (W24_PH * W24_PW * W24_CGS)         // 1296 float4 per stage
+#define W24_SLOTS ((W24_F4 + IG_THREADS - 1) / IG_THREADS)
+#define W24_LDR 36
+#define W24_RED (8 * 32 * W24_LDR)                 // [xi 4][col 2][tile 32][36] floats (36.9 KB)
+#define W24_MAIN (2 * W24_STAGE > W24_RED ? 2 * W24_STAGE : W24_RED)
+#define W24_SMEM_FLOATS (W24_MAIN + 16)
+
+typedef float w24_v2 __attribute__((ext_vector_type(2)));
+typedef float w24_v4 __attribute__((ext_vector_type(4)));
+
+struct W24Grid {
+    int tilesX, tilesY, ntb;
+    unsigned mNtb, mTx, mTy;
+};
+__device__ __forceinline__ int w24_div(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
+__device__ __forceinline__ w24_v4 w24_lds4(const float* p) { return *reinterpret_cast<const w24_v4*>(p); }
+
+// Output columns 2p, 2p+1 of one accumulator group (32 tiles x 32 channels, the wave's six frequencies): A4 in registers,
+// A2 across the waves through `red`, then scale / shift (+ residual) + activation and float4 NHWC stores.
+template <int P>
+__device__ __forceinline__ void w24_output_cols(const ConvArgs& a, float* red, const f32x16 (&acc)[6], int xi, int h, int m, int tid,
+                                                int b, int y0, int x0, int tile)
+{
+    const float* const a_res = a.res;
+    const bool relu = a.act == CP_ACT_RELU;
+    const bool vec_ok = (a.outLd & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
+                        (!a_res || ((a.resLd & 3) == 0 && (((size_t)a_res) & 15) == 0));
+    float* wp = red + (xi * 64 + m) * W24_LDR + 4 * h;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w24_v4 q[6];
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) q[nu] = (w24_v4){acc[nu][4 * j], acc[nu][4 * j + 1], acc[nu][4 * j + 2], acc[nu][4 * j + 3]};
+        const w24_v4 s1 = q[1] + q[2], d1 = q[1] - q[2], s2 = q[3] + q[4], d2 = q[3] - q[4];
+        w24_v4 c0, c1;
+        if constexpr (P == 0) {
+            c0 = (q[0] + s1) + s2;                       // column 0:  m0 + m1 + m2 + m3 + m4
+            c1 = d1 + 2.f * d2;                          // column 1:  m1 - m2 + 2 m3 - 2 m4
+        } else {
+            c0 = s1 + 4.f * s2;                          // column 2:  m1 + m2 + 4 m3 + 4 m4
+            c1 = (d1 + 8.f * d2) + q[5];                 // column 3:  m1 - m2 + 8 m3 - 8 m4 + m5
+        }
+        *reinterpret_cast<w24_v4*>(wp + 8 * j) = c0;
+        *reinterpret_cast<w24_v4*>(wp + 32 * W24_LDR + 8 * j) = c1;
+    }
+    int itn[2], itox[2], itoy[2], itrd[2];
+    bool itok[2], itvec[2];
+    size_t itpix[2];
+    w24_v4 sc[2], sh[2], rr[2][2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int item = tid + it * IG_THREADS;
+        const int n4 = item & 7, bb = (item >> 3) & 1, mi = item >> 4;
+        itn[it] = tile * 32 + n4 * 4;
+        itox[it] = x0 + 4 * (mi & 3) + 2 * P + bb;
+        itoy[it] = y0 + 2 * (mi >> 2);
+        itrd[it] = (bb * 32 + mi) * W24_LDR + n4 * 4;
+        itok[it] = itox[it] < a.W && itn[it] < a.Cout && itoy[it] < a.H;
+        itvec[it] = itok[it] && vec_ok && itn[it] + 3 < a.Cout;
+        itpix[it] = ((size_t)b * a.H + itoy[it]) * a.W + itox[it];
+        if (itvec[it]) {
+            sc[it] = *reinterpret_cast<const w24_v4*>(a.scale + itn[it]);
+            sh[it] = *reinterpret_cast<const w24_v4*>(a.shift + itn[it]);
+            if (a_res) {
+                rr[it][0] = *reinterpret_cast<const w24_v4*>(a_res + itpix[it] * a.resLd + itn[it]);
+                if (itoy[it] + 1 < a.H) rr[it][1] = *reinterpret_cast<const w24_v4*>(a_res + (itpix[it] + a.W) * a.resLd + itn[it]);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        if (!itok[it]) continue;
+        const float* rp = red + itrd[it];
+        const w24_v4 q0 = w24_lds4(rp), q1 = w24_lds4(rp + 64 * W24_LDR), q2 = w24_lds4(rp + 128 * W24_LDR), q3 = w24_lds4(rp + 192 * W24_LDR);
+        w24_v4 yv[2];
+        yv[0] = (q0 + q1) + q2;
+        yv[1] = (q1 - q2) - q3;
+        const int n = itn[it];
+        if (itvec[it]) {
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                if (itoy[it] + aa >= a.H) continue;
+                const size_t opix = itpix[it] + (size_t)aa * a.W;
+                w24_v4 v = __builtin_elementwise_fma(yv[aa], sc[it], sh[it]);
+                if (a_res) v += rr[it][aa];
+                if (relu) v = (w24_v4){cp_relu(v.x), cp_relu(v.y), cp_relu(v.z), cp_relu(v.w)};
+                else if (a.act != CP_ACT_NONE) { v.x = cp_act(v.x, a.act); v.y = cp_act(v.y, a.act); v.z = cp_act(v.z, a.act); v.w = cp_act(v.w, a.act); }
+                *reinterpret_cast<w24_v4*>(a.out + opix * a.outLd + n) = v;
+            }
+        } else {
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa) {
+                if (itoy[it] + aa >= a.H) continue;
+                const size_t opix = itpix[it] + (size_t)aa * a.W;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (n + k >= a.Cout) break;
+                    float w_ = yv[aa][k] * a.scale[n + k] + a.shift[n + k];
+                    if (a_res) w_ += a_res[opix * a.resLd + n + k];
+                    w_ = cp_act(w_, a.act);
+                    a.out[opix * a.outLd + n + k] = w_;
+                }
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const ConvArgs a, const W24Grid gd)
+{
+    constexpr int CPS = W24_KS / 8;                    // chunks per stage
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, m = lane & 31;
+    const int NTILES = (a.Cout + 31) >> 5;
+    int t_ = ig_xcd_remap(blockIdx.x, gridDim.x), q_;
+    q_ = w24_div(t_, gd.ntb, gd.mNtb); const int nb = t_ - q_ * gd.ntb; t_ = q_;
+    q_ = w24_div(t_, gd.tilesX, gd.mTx); const int tx = t_ - q_ * gd.tilesX; t_ = q_;
+    q_ = w24_div(t_, gd.tilesY, gd.mTy); const int ty = t_ - q_ * gd.tilesY;
+    const int b = q_;
+    const int y0 = ty * 16, x0 = tx * 16;
+    const int C = a.srcC[0], ld = a.srcLd[0];
+    const int KC = C >> 3;
+    const float* __restrict__ x = a.src[0];
+    const bool interior = y0 >= 1 && y0 + 17 <= a.H && x0 >= 1 && x0 + 17 <= a.W;
+
+    // ---- staging slots (fixed per thread): patch pixel pp, channel group q
+    int go[W24_SLOTS], lo[W24_SLOTS];
+    bool ok[W24_SLOTS];
+#pragma unroll
+    for (int s = 0; s < W24_SLOTS; ++s) {
+        const int idx = tid + s * IG_THREADS;
+        const int pp = idx / W24_CGS, q = idx % W24_CGS;
+        const int py = pp / W24_PW, px = pp - py * W24_PW;
+        const int gy = y0 - 1 + py, gx = x0 - 1 + px;
+        const bool inl = idx < W24_F4;
+        ok[s] = inl && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
+        go[s] = ok[s] ? ((b * a.H + gy) * a.W + gx) * ld + q * 4 : 0;
+        lo[s] = inl ? ((q * W24_PH + py) * W24_PWP + (px ^ ((py >> 1) & 3))) * 4 : -1;
+    }
+    float4 rg[W24_SLOTS];
+    auto stage_load = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int s = 0; s < W24_SLOTS; ++s) rg[s] = ig_ldg4(x + go[s] + c0);
+    };
+    auto stage_store = [&](float* buf) __attribute__((always_inline)) {
+        if (interior) {
+#pragma unroll
+            for (int s = 0; s < W24_SLOTS; ++s)
+                if (lo[s] >= 0) *reinterpret_cast<float4*>(buf + lo[s]) = rg[s];
+        } else {
+#pragma unroll
+            for (int s = 0; s < W24_SLOTS; ++s)
+                if (lo[s] >= 0) {
+                    float4 v = rg[s];
+                    if (!ok[s]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *reinterpret_cast<float4*>(buf + lo[s]) = v;
+                }
+        }
+    };
+
+    // ---- wave's transform row (F(2,3)): t[j] = d[rA][j] + sg * d[rB][j]
+    const int rA = xi == 0 ? 0 : (xi == 2 ? 2 : 1);
+    const int rB = xi == 2 ? 1 : (xi == 3 ? 3 : 2);
+    const float sg1 = xi == 1 ? 1.f : -1.f;
+    const w24_v2 sg = {sg1, sg1};
+    const int tyy = m >> 2, txx = m & 3;
+    const int sA = (tyy + (rA >> 1)) & 3, sB = (tyy + (rB >> 1)) & 3;     // swizzle of the lane's two patch rows
+    const int baseA = ((2 * tyy + rA) * W24_PWP + 4 * txx) * 4 + h * W24_CG;
+    const int baseB = ((2 * tyy + rB) * W24_PWP + 4 * txx) * 4 + h * W24_CG;
+    int offA[4], offB[4];                      // column jj of an aligned group of four lives in slot jj ^ s
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) { offA[jj] = baseA + ((jj ^ sA) << 2); offB[jj] = baseB + ((jj ^ sB) << 2); }
+
+    // ---- U fragments: [xi][ntile][kc][nu 6][lane][4]
+    int tile = nb;
+    if (tile >= NTILES) tile = NTILES - 1;
+    const float* ub = a.w + ((size_t)(xi * NTILES + tile) * KC) * 1536 + lane * 4;
+    float4 bq[2][6];
+    auto load_u = [&](int kc, float4 (&dst)[6]) __attribute__((always_inline)) {
+        const int kk = kc < KC ? kc : KC - 1;
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) dst[nu] = ig_ldg4(ub + (size_t)kk * 1536 + nu * 256);
+    };
+
+    const int nstage = C / W24_KS;
+    stage_load(0);
+    load_u(0, bq[0]);
+    stage_store(smem);
+    if (tid < 4) *reinterpret_cast<float4*>(smem + W24_MAIN + tid * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    f32x16 acc[6];
+    {
+        const w24_v4* zp = reinterpret_cast<const w24_v4*>(smem + W24_MAIN);
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                w24_v4 z = zp[r4];
+                asm volatile("" : "+v"(z));
+                acc[nu][4 * r4] = z.x; acc[nu][4 * r4 + 1] = z.y; acc[nu][4 * r4 + 2] = z.z; acc[nu][4 * r4 + 3] = z.w;
+            }
+    }
+
+#pragma unroll 1
+    for (int st = 0; st < nstage; ++st) {
+        const float* buf = smem + (st & 1) * W24_STAGE;
+        const bool more = st + 1 < nstage;
+#pragma unroll
+        for (int ch = 0; ch < CPS; ++ch) {
+            const float* pc = buf + ch * 2 * W24_CG;
+            w24_v2 tl[6], th[6];
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                const w24_v4 da = w24_lds4(pc + offA[j & 3] + (j >> 2) * 16);
+                const w24_v4 db = w24_lds4(pc + offB[j & 3] + (j >> 2) * 16);
+                tl[j] = __builtin_elementwise_fma(sg, db.xy, da.xy);
+                th[j] = __builtin_elementwise_fma(sg, db.zw, da.zw);
+            }
+            // V = t B4: six column frequencies per channel pair, 12 packed ops per pair
+            w24_v2 vl[6], vh[6];
+            {
+                const w24_v2 k4 = {4.f, 4.f}, kn4 = {-4.f, -4.f}, kn5 = {-5.f, -5.f}, k2 = {2.f, 2.f}, kn2 = {-2.f, -2.f};
+                const w24_v2 al = __builtin_elementwise_fma(kn4, tl[2], tl[4]), ah = __builtin_elementwise_fma(kn4, th[2], th[4]);
+                const w24_v2 bl = __builtin_elementwise_fma(kn4, tl[1], tl[3]), bh = __builtin_elementwise_fma(kn4, th[1], th[3]);
+                const w24_v2 cl = tl[4] - tl[2], chh = th[4] - th[2];
+                const w24_v2 fl = tl[3] - tl[1], fh = th[3] - th[1];
+                vl[0] = __builtin_elementwise_fma(k4, tl[0], __builtin_elementwise_fma(kn5, tl[2], tl[4]));
+                vh[0] = __builtin_elementwise_fma(k4, th[0], __builtin_elementwise_fma(kn5, th[2], th[4]));
+                vl[1] = al + bl; vh[1] = ah + bh;
+                vl[2] = al - bl; vh[2] = ah - bh;
+                vl[3] = __builtin_elementwise_fma(k2, fl, cl); vh[3] = __builtin_elementwise_fma(k2, fh, chh);
+                vl[4] = __builtin_elementwise_fma(kn2, fl, cl); vh[4] = __builtin_elementwise_fma(kn2, fh, chh);
+                vl[5] = __builtin_elementwise_fma(k4, tl[1], __builtin_elementwise_fma(kn5, tl[3], tl[5]));
+                vh[5] = __builtin_elementwise_fma(k4, th[1], __builtin_elementwise_fma(kn5, th[3], th[5]));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) {
+                if (nu == 1) {                                            // next chunk's U: after 4 of the 24 MFMAs
+                    load_u(st * CPS + ch + 1, bq[(ch + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (nu == 3 && ch == 0 && more) {                         // next stage's patch: younger than every U load used in this stage
+                    stage_load((st + 1) * W24_KS);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (nu == 4 && ch == CPS - 1 && more) {                   // hand-over into the other stage buffer from inside the MFMA block
+                    stage_store(smem + ((st + 1) & 1) * W24_STAGE);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                const float4 bb = bq[ch & 1][nu];
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.x, vl[nu].x, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.y, vl[nu].y, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.z, vh[nu].x, acc[nu], 0, 0, 0);
+                acc[nu] = __builtin_amdgcn_mfma_f32_32x32x2f32(bb.w, vh[nu].y, acc[nu], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    if (nb < NTILES) {            // block-uniform (ragged last channel block computes a duplicate that is never stored)
+        w24_output_cols<0>(a, smem, acc, xi, h, m, tid, b, y0, x0, nb);
+        __syncthreads();
+        w24_output_cols<1>(a, smem, acc, xi, h, m, tid, b, y0, x0, nb);
+    }
+}
+
+static unsigned w24_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
+
+// a.w = F(2x4) Winograd-domain weights from cp_winograd24_pack_f32.  Returns -1 when the shape is not eligible.
+int cp_launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s)
+{
+    const bool ok = a.nsrc == 1 && a.kh == 3 && a.kw == 3 && a.sy == 1 && a.sx == 1 && a.py == 1 && a.px == 1 &&
+                    !a.outNCHW && a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.Ho == a.H && a.Wo == a.W &&
+                    a.OH == a.H && a.OW == a.W && a.srcC[0] % 16 == 0 && a.srcLd[0] % 4 == 0 && a.ksplit == 1 &&
+                    (((size_t)a.src[0] | (size_t)a.w) & 15) == 0 &&
+                    (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
+    if (!ok) return -1;
+    const int smem = W24_SMEM_FLOATS * 4;
+    static CpLdsGuard guard;
+    if (smem > 64 * 1024) {
+        const hipError_t e = guard.ensure((const void*)conv3x3_wino24_kernel, smem);
+        if (e != hipSuccess) { cp_set_error("conv3x3_winograd24: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
+    }
+    W24Grid gd;
+    gd.tilesX = cp_cdiv(a.W, 16); gd.tilesY = cp_cdiv(a.H, 16);
+    gd.ntb = (a.Cout + 31) / 32;
+    gd.mNtb = w24_magic(gd.ntb); gd.mTx = w24_magic(gd.tilesX); gd.mTy = w24_magic(gd.tilesY);
+    const long long grid = (long long)a.B * gd.tilesX * gd.tilesY * gd.ntb;
+    const long long dmax = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
+    if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd24: grid %lld too large", grid); return 1; }
+    hipLaunchKernelGGL(conv3x3_wino24_kernel, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
+    cp_note_kernel("conv3x3_wino24_kernel");
+    return 0;
+}
+
+// ---- weight transform: packed direct weights [rows >= Cout][9*C] (k = (ky*3+kx)*C + c)  ->  U = G2 g G4^T in fragment order
+//   value(lane, j) = U[xi][nu][n = ntile*32 + lane%32][c = kc*8 + (lane/32)*4 + j]      (zero for n >= Cout)
+__global__ void wino24_pack_kernel(const float* __restrict__ w, float* __restrict__ u, int C, int Cout, int ntiles, long long total)
+{
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int KC = C >> 3;
+    long long t = idx;
+    const int j = (int)(t & 3); t >>= 2;
+    const int lane = (int)(t & 63); t >>= 6;
+    const int nu = (int)(t % 6); t /= 6;
+    const int kc = (int)(t % KC); t /= KC;
+    const int nt = (int)(t % ntiles);
+    const int xi = (int)(t / ntiles);
+    const int n = nt * 32 + (lane & 31), c = kc * 8 + (lane >> 5) * 4 + j;
+    float r = 0.f;
+    if (n < Cout) {
+        const double G2[4][3] = {{1.0, 0.0, 0.0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0.0, 0.0, 1.0}};
+        const double G4[6][3] = {{1.0 / 4, 0.0, 0.0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                 {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0.0, 0.0, 1.0}};
+        const float* g = w + (size_t)n * 9 * C + c;
+        double accd = 0.0;
+        for (int ky = 0; ky < 3; ++ky)
+            for (int kx = 0; kx < 3; ++kx) accd += G2[xi][ky] * (double)g[(ky * 3 + kx) * C] * G4[nu][kx];
+        r = (float)accd;
+    }
+    u[idx] = r;
+}
+
+extern "C" size_t cp_winograd24_weight_floats(int C, int Cout)
+{
+    if (C <= 0 || Cout <= 0 || C % 8) return 0;
+    return (size_t)24 * ((Cout + 31) / 32) * 32 * C;
+}
+
+extern "C" int cp_winograd24_pack_f32(const float* w, float* u, int C, int Cout, void* stream)
+{
+    CP_CHECK_ARG(w && u, "winograd24_pack: null pointer");
+    CP_CHECK_ARG(C > 0 && C % 16 == 0 && Cout > 0, "winograd24_pack: C=%d must be a positive multiple of 16 (Cout=%d)", C, Cout);
+    const int ntiles = (Cout + 31) / 32;
+    const long long total = (long long)cp_winograd24_weight_floats(C, Cout);
+    hipLaunchKernelGGL(wino24_pack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, u, C, Cout,
+                       ntiles, total);
+    CP_CHECK_LAUNCH("wino24_pack_kernel");
+    return 0;
+}

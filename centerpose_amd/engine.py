@@ -142,9 +142,19 @@ class PlanBuilder(nets.Graph):
     def bn(self, name):
         return tuple(self.w("%s.%s" % (name, s)) for s in ("weight", "bias", "running_mean", "running_var"))
 
-    def wino(self, wp, cin, cout, k=3, stride=1, pad=1, nsrc=1, key=None):
+    def wino(self, wp, cin, cout, k=3, stride=1, pad=1, nsrc=1, key=None, hw=None):
         """Winograd-domain weights for an eligible 3x3/s1/p1 layer, else None (direct kernel).  `key` (the layer's parameter
-        name): share the transformed weights between the plans of one model."""
+        name): share the transformed weights between the plans of one model.  hw = (H, W) of the layer: lets
+        `ops.wino24_wanted` pick the F(2x4,3x3) kernel -> ("wino24", weights)."""
+        if self.winograd and hw is not None and ops.wino_eligible(cin, k, stride, pad, nsrc) and \
+                ops.wino24_wanted(self.B, hw[0], hw[1], cin, cout):
+            ck = ("u24", key, cin, cout)
+            hit = self.const_cache.get(ck) if key is not None else None
+            if hit is None:
+                hit = ops.pack_wino24_weight(wp, cin, cout)
+                if key is not None:
+                    self.const_cache[ck] = hit
+            return ("wino24", hit)
         if self.winograd and ops.wino_eligible(cin, k, stride, pad, nsrc):
             ck = ("u", key, cin, cout)
             hit = self.const_cache.get(ck) if key is not None else None
@@ -160,8 +170,13 @@ class PlanBuilder(nets.Graph):
 
     def add_wino(self, name, flops, x, wp, u, sc, sh, out, cout, act, res=None):
         """One Winograd 3x3 launch -- or, for a map too small to fill the chip (ops.wino_ksplit) and no residual, a split-C
-        launch into a workspace of raw partial outputs plus the fixed-order reduction that applies scale / shift / activation."""
+        launch into a workspace of raw partial outputs plus the fixed-order reduction that applies scale / shift / activation.
+        `u` = F(2x2) weights, or ("wino24", F(2x4) weights) from `self.wino` for the layers `ops.wino24_wanted` picks."""
         B, H, W, cin = x.shape
+        if isinstance(u, tuple):
+            self.add("wino24", name, flops, ops.conv2d_launch([x], wp, sc, sh, out, kh=3, kw=3, stride=1, pad=1, cout=cout, act=act,
+                                                              res=res, wino=u[1], tile=ops.WINO24))
+            return
         S = ops.wino_ksplit(B, H, W, cin, cout) if (self.wino_splitc and res is None) else 1
         if S > 1:
             ld, M = out.shape[3], B * H * W
@@ -194,7 +209,7 @@ class PlanBuilder(nets.Graph):
         rt = res.t if res is not None else None
         ci = sum(a.C for a in xs)
         cip = ci if stem else sum(a.t.shape[3] for a in xs)               # physical K per tap
-        u = None if stem else self.wino(wp, cip, co, k, stride, pad, len(xs), key=conv)
+        u = None if stem else self.wino(wp, cip, co, k, stride, pad, len(xs), key=conv, hw=(x.H, x.W))
         flops = 2 * Ho * Wo * co * ci * k * k
         if u is not None:
             self.add_wino(conv, flops, srcs[0], wp, u, sc, sh, out.t, out.t.shape[3], self.act_code(relu), rt)
@@ -225,7 +240,7 @@ class PlanBuilder(nets.Graph):
         out = self.buf(x.H, x.W, co)
         wp = ops.pack_conv_weight(self.expand_in(self.w(conv + ".weight"), [x]))
         sc, sh = ops.fold_bn(co, self.bn(bn), self.w(conv + ".bias"), self.dev)
-        uom = self.wino(wom, x.t.shape[3], 32, key=conv + ".conv_offset_mask")
+        uom = self.wino(wom, x.t.shape[3], 32, key=conv + ".conv_offset_mask", hw=(x.H, x.W))
         if uom is not None:
             self.add_wino(conv + ".conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9, x.t, wom, uom, som, hom, om.t, 32, ops.ACT_NONE)
         else:

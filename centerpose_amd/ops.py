@@ -5,6 +5,7 @@ only ``stride(2)`` -- floats between pixels -- is passed down).  Weight packing 
 K-major repack) happens once at plan time, on the device, with plain torch ops.
 """
 import ctypes
+import os
 
 import torch
 
@@ -280,6 +281,34 @@ def pack_wino_weight(wp, cin, cout):
     u = torch.empty((n,), dtype=torch.float32, device=wp.device)
     _lib.check(L.cp_winograd_pack_f32(_lib.ptr(wp), _lib.ptr(u), cin, cout, _lib.stream()), "cp_winograd_pack_f32")
     return u
+
+
+def pack_wino24_weight(wp, cin, cout):
+    """packed direct 3x3 weights [ldw, 9*cin] (device) -> F(2x4,3x3) Winograd-domain U = G2 g G4^T in the fragment order of
+    conv3x3_wino24.hip ([xi][ntile][kc][nu 6][lane][4]); launches that carry it pass `tile=WINO24` to conv2d_launch."""
+    L = _lib.lib()
+    assert wp.shape[1] == 9 * cin and wp.shape[0] >= cout and wp.is_contiguous()
+    L.cp_winograd24_weight_floats.restype = ctypes.c_size_t
+    n = L.cp_winograd24_weight_floats(cin, cout)
+    assert n > 0, "winograd: C must be a multiple of 16"
+    u = torch.empty((n,), dtype=torch.float32, device=wp.device)
+    _lib.check(L.cp_winograd24_pack_f32(_lib.ptr(wp), _lib.ptr(u), cin, cout, _lib.stream()), "cp_winograd24_pack_f32")
+    return u
+
+
+WINO24 = 24          # cp_conv_desc.tile code of the F(2x4,3x3) kernel
+
+
+def wino24_wanted(B, H, W, cin, cout):
+    """Which 3x3/s1 layers take the F(2x4,3x3) kernel instead of F(2x2,3x3).  CP_WINO24 = "0": none; otherwise the rule
+    cin >= MINC, cout >= MINCOUT, 16x16-pixel x 32-channel blocks >= MINBLOCKS, with (MINC, MINCOUT, MINBLOCKS) from
+    CP_WINO24_RULE (default below, from the same-box A/B of DESIGN 7.1).  Launches under the block floor stay on the F(2x2)
+    kernel, whose 8x16-pixel blocks and split-C fill the chip on small maps."""
+    if os.environ.get("CP_WINO24", "1") == "0" or cin % 16 or cin < 32:
+        return False
+    minc, mincout, minblocks = (int(v) for v in os.environ.get("CP_WINO24_RULE", "32,16,256").split(","))
+    blocks = B * ((H + 15) // 16) * ((W + 15) // 16) * ((cout + 31) // 32)
+    return cin >= minc and cout >= mincout and blocks >= minblocks
 
 
 def dcn_v2(x, om, wp, scale, shift, out, **kw):

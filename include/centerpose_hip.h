@@ -70,9 +70,13 @@ int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w
  *   -> u [cp_winograd_weight_floats(C, Cout)] = G g G^T in the kernel's MFMA B-fragment order; C % 16 == 0.
  * cp_conv3x3_winograd_f32: d as for cp_conv2d_f32 with nsrc = 1, kh = kw = 3, stride 1, pad 1, NHWC in/out
  *   (returns 1 for any other shape); d->tile: 0 = auto, MT*10+NT in {11, 12, 21} forces a block shape, 64xx the
- *   V-stationary kernel for 64 input channels with xx channel-tile groups per spatial tile. */
+ *   V-stationary kernel for 64 input channels with xx channel-tile groups per spatial tile; 24 = the F(2x4,3x3) kernel
+ *   (conv3x3_wino24.hip: 2x4 output tiles, 24 multiplies per tile and (cin, cout) = 3 per output instead of 4; `u` must then
+ *   come from cp_winograd24_pack_f32 -- same argument meaning, [cp_winograd24_weight_floats(C, Cout)] floats; no split-C). */
 size_t cp_winograd_weight_floats(int C, int Cout);
 int cp_winograd_pack_f32(const float* w, float* u, int C, int Cout, void* stream);
+size_t cp_winograd24_weight_floats(int C, int Cout);
+int cp_winograd24_pack_f32(const float* w, float* u, int C, int Cout, void* stream);
 int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
                             const float* res, float* out, void* stream);
 

@@ -544,6 +544,73 @@ def test_conv3x3_winograd_fuzz_vs_direct_kernel():
         _close(outs[1], outs[0], 1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,hw,B", [(32, 32, (16, 16), 1), (64, 64, (20, 28), 3), (32, 27, (19, 16), 2), (48, 128, (9, 35), 2),
+                                           (128, 192, (16, 16), 2), (256, 96, (8, 8), 2), (128, 128, (64, 64), 2), (16, 40, (33, 17), 1),
+                                           (512, 64, (16, 16), 1)])
+def test_conv3x3_winograd24_kernel(cin, cout, hw, B):
+    """fused Winograd F(2x4,3x3) kernel (conv3x3_wino24.hip, cp_conv_desc.tile = 24): odd sizes, ragged 16x16 tiles, residual,
+    ragged channel tiles, scalar-store tail, long channel loops; against the torch-CPU fp32 direct convolution at the same
+    2e-4 * max|ref| as the F(2x2) kernel (F(4,3)'s larger transform constants cost about one digit: ~1e-5 measured)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(11 * cin + cout)
+    H, W = hw
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bn = _rand_bn(g, cout)
+    res = torch.randn(B, cout, H, W, generator=g) if cout != 96 else None
+    y = _ref_bn(F.conv2d(x, w, None, 1, 1), bn)
+    ref = F.relu(y + res) if res is not None else y
+    wp = ops.pack_conv_weight(w.cuda())
+    u = ops.pack_wino24_weight(wp, cin, cout)
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    ld = 32 if cout == 27 else cout
+    buf = torch.full((B, H, W, ld), float("nan"), device="cuda")
+    out = buf[..., :cout]
+    resn = res.permute(0, 2, 3, 1).contiguous().cuda() if res is not None else None
+    la = ops.conv2d_launch([_nhwc(x)], wp, sc, sh, out, kh=3, kw=3, stride=1, pad=1, cout=cout,
+                           act=ops.ACT_RELU if res is not None else ops.ACT_NONE, res=resn, tile=ops.WINO24, wino=u)
+    la.run()
+    assert la.kernel == "conv3x3_wino24_kernel"
+    _close(out.permute(0, 3, 1, 2), ref)
+    if ld != cout:
+        assert torch.isnan(buf[..., cout:]).all()      # nothing stored past Cout
+    first = out.clone()
+    la.run()
+    assert torch.equal(first, out)
+
+
+def test_conv3x3_winograd24_fuzz_vs_direct_kernel():
+    """Seeded random shapes (odd H/W, ragged channel tiles, strided input / output / residual views, every activation): the
+    F(2x4) kernel against the direct halo-patch kernel on the same buffers."""
+    from centerpose_amd import ops
+    rng = np.random.RandomState(24)
+    g = torch.Generator().manual_seed(24)
+    for it in range(12):
+        B = int(rng.randint(1, 4))
+        H, W = int(rng.randint(3, 41)), int(rng.randint(3, 45))
+        cin = int(rng.choice([32, 48, 64, 96]))
+        cout = int(rng.choice([16, 27, 32, 40, 64, 100, 128]))
+        act = int(rng.choice([ops.ACT_NONE, ops.ACT_RELU, ops.ACT_SIGMOID]))
+        in_ld, out_ld = cin + 16 * int(rng.randint(0, 2)), ops.round_up(cout, 4) + 4 * int(rng.randint(0, 3))
+        xb = torch.randn(B, H, W, in_ld, generator=g).cuda()
+        x = xb[..., in_ld - cin:]
+        w = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).cuda()
+        wp = ops.pack_conv_weight(w)
+        u = ops.pack_wino24_weight(wp, cin, cout)
+        sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in _rand_bn(g, cout)))
+        use_res = bool(rng.randint(0, 2))
+        resb = torch.randn(B, H, W, out_ld, generator=g).cuda() if use_res else None
+        res = resb[..., :cout] if use_res else None
+        outs = []
+        for wino in (None, u):
+            ob = torch.full((B, H, W, out_ld), float("nan"), device="cuda")
+            ops.conv2d([x], wp, sc, sh, ob[..., :cout], kh=3, kw=3, stride=1, pad=1, cout=cout, act=act, res=res,
+                       tile=ops.WINO24 if wino is not None else 0, wino=wino)
+            assert torch.isnan(ob[..., cout:]).all(), "case %d wrote past Cout" % it
+            outs.append(ob[..., :cout])
+        _close(outs[1], outs[0], 1e-4)
+
+
 @pytest.mark.parametrize("cout,s,hw", [(16, 1, (40, 72)), (64, 2, (37, 70)), (16, 1, (512, 512)), (64, 2, (128, 96))])
 def test_stem7x7_kernel(cout, s, hw):
     """dedicated 7x7 stem (pose_dla_dcn.py:228-232 / msra_resnet.py:118-121) vs torch-CPU."""

@@ -1,5 +1,5 @@
 """Micro-benchmark of single conv / dcn launches (GPU box).
-usage: bench_conv.py name[,name...] [tile,...]   names: see CASES; tile -(MT*10+NT) = Winograd kernel variant (-11, -12, -21)"""
+usage: bench_conv.py name[,name...] [tile,...]   names: see CASES; tile -(MT*10+NT) = Winograd kernel variant (-11, -12, -21), -24 = F(2x4,3x3)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -49,7 +49,7 @@ def run(name, tile=0, iters=20):
         fn = lambda: ops.conv2d([x], wp, sc, sh, out, kh=k, kw=k, stride=s, pad=p, cout=Co, act=1, in_nchw=True, tile=tile)
     elif kind == "conv":
         x = torch.randn(B, H, W, Ci, device="cuda", generator=g)
-        u = ops.pack_wino_weight(wp, Ci, co_store) if tile < 0 else None
+        u = (ops.pack_wino24_weight if tile == -24 else ops.pack_wino_weight)(wp, Ci, co_store) if tile < 0 else None      # -24: F(2x4,3x3)
         fn = lambda: ops.conv2d([x], wp, sc, sh, out, kh=k, kw=k, stride=s, pad=p, cout=co_store, act=1 + int(os.environ.get('CP_ABL', '0')), tile=abs(tile) if u is not None else tile, wino=u)
     else:
         x = torch.randn(B, H, W, Ci, device="cuda", generator=g)
