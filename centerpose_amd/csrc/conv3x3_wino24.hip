@@ -22,6 +22,7 @@
 //     output columns per pass (the F(2x2) kernel's reduction buffer, twice), then scale / shift + residual + activation.
 // fp32 throughout.  F(4,3) has larger transform constants than F(2,3): the measured error against an fp64 convolution is in
 // tools/wino_check.py / DESIGN.md 7.1.
+#include <type_traits>
 #include "igemm.h"
 
 #define W24_PH 18
@@ -139,6 +140,10 @@ __device__ __forceinline__ void w24_output_cols(const ConvArgs& a, float* red, c
     }
 }
 
+// Measured and NOT kept (same box, same process, tools/bench_conv.py): pinning the transform in front of the MFMA block with empty
+// asm statements, the literal -5 form of the column transform (two scalar v_fma_f32 per packed one), a run-time stage-buffer
+// offset (13 more address VALU per stage) -- all within the run-to-run noise of +-2 %: the kernel is not bound by its VALU count
+// (PMC: 63 % of a wave's cycles wait for issue behind the other resident waves / barriers, 20 % sit in s_waitcnt).
 __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const ConvArgs a, const W24Grid gd)
 {
     constexpr int CPS = W24_KS / 8;                    // chunks per stage
@@ -177,14 +182,15 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const Con
         for (int s = 0; s < W24_SLOTS; ++s) rg[s] = ig_ldg4(x + go[s] + c0);
     };
     auto stage_store = [&](float* buf) __attribute__((always_inline)) {
+        // slots 0 .. SLOTS-2 are inside the patch for every thread ((s + 1) * 256 <= F4): only the last one needs the check
         if (interior) {
 #pragma unroll
             for (int s = 0; s < W24_SLOTS; ++s)
-                if (lo[s] >= 0) *reinterpret_cast<float4*>(buf + lo[s]) = rg[s];
+                if ((s + 1) * IG_THREADS <= W24_F4 || lo[s] >= 0) *reinterpret_cast<float4*>(buf + lo[s]) = rg[s];
         } else {
 #pragma unroll
             for (int s = 0; s < W24_SLOTS; ++s)
-                if (lo[s] >= 0) {
+                if ((s + 1) * IG_THREADS <= W24_F4 || lo[s] >= 0) {
                     float4 v = rg[s];
                     if (!ok[s]) v = make_float4(0.f, 0.f, 0.f, 0.f);
                     *reinterpret_cast<float4*>(buf + lo[s]) = v;
@@ -235,9 +241,12 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const Con
             }
     }
 
-#pragma unroll 1
-    for (int st = 0; st < nstage; ++st) {
-        const float* buf = smem + (st & 1) * W24_STAGE;
+    // One stage = 16 channels = two 8-channel chunks out of stage buffer BUF (a compile-time constant: the stage loop is unrolled
+    // by two so that every LDS address is lane base + immediate -- as a run-time buffer offset the compiler spent 13 VALU per
+    // stage on ds_read / ds_write addresses, and every VALU instruction takes issue cycles the matrix pipe cannot use).
+    auto stage = [&](int st, auto bufc) __attribute__((always_inline)) {
+        constexpr int BUF = decltype(bufc)::value;
+        const float* buf = smem + BUF * W24_STAGE;
         const bool more = st + 1 < nstage;
 #pragma unroll
         for (int ch = 0; ch < CPS; ++ch) {
@@ -250,22 +259,22 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const Con
                 tl[j] = __builtin_elementwise_fma(sg, db.xy, da.xy);
                 th[j] = __builtin_elementwise_fma(sg, db.zw, da.zw);
             }
-            // V = t B4: six column frequencies per channel pair, 12 packed ops per pair
+            // V = t B4: six column frequencies per channel pair in 12 packed ops, written so that every constant is an inline
+            // operand of v_pk_fma_f32 (4, -4, 2, -2): 4 t0 - 5 t2 + t4 = 4 (t0 - t2) + (t4 - t2), 4 t1 - 5 t3 + t5 = (t5 - t3) - 4 (t3 - t1)
+            // (with the literal -5 the compiler split each of those into two scalar v_fma_f32)
             w24_v2 vl[6], vh[6];
             {
-                const w24_v2 k4 = {4.f, 4.f}, kn4 = {-4.f, -4.f}, kn5 = {-5.f, -5.f}, k2 = {2.f, 2.f}, kn2 = {-2.f, -2.f};
+                const w24_v2 k4 = {4.f, 4.f}, kn4 = {-4.f, -4.f}, k2 = {2.f, 2.f}, kn2 = {-2.f, -2.f};
                 const w24_v2 al = __builtin_elementwise_fma(kn4, tl[2], tl[4]), ah = __builtin_elementwise_fma(kn4, th[2], th[4]);
                 const w24_v2 bl = __builtin_elementwise_fma(kn4, tl[1], tl[3]), bh = __builtin_elementwise_fma(kn4, th[1], th[3]);
                 const w24_v2 cl = tl[4] - tl[2], chh = th[4] - th[2];
                 const w24_v2 fl = tl[3] - tl[1], fh = th[3] - th[1];
-                vl[0] = __builtin_elementwise_fma(k4, tl[0], __builtin_elementwise_fma(kn5, tl[2], tl[4]));
-                vh[0] = __builtin_elementwise_fma(k4, th[0], __builtin_elementwise_fma(kn5, th[2], th[4]));
+                vl[0] = __builtin_elementwise_fma(k4, tl[0] - tl[2], cl); vh[0] = __builtin_elementwise_fma(k4, th[0] - th[2], chh);
+                vl[5] = __builtin_elementwise_fma(kn4, fl, tl[5] - tl[3]); vh[5] = __builtin_elementwise_fma(kn4, fh, th[5] - th[3]);
                 vl[1] = al + bl; vh[1] = ah + bh;
                 vl[2] = al - bl; vh[2] = ah - bh;
                 vl[3] = __builtin_elementwise_fma(k2, fl, cl); vh[3] = __builtin_elementwise_fma(k2, fh, chh);
                 vl[4] = __builtin_elementwise_fma(kn2, fl, cl); vh[4] = __builtin_elementwise_fma(kn2, fh, chh);
-                vl[5] = __builtin_elementwise_fma(k4, tl[1], __builtin_elementwise_fma(kn5, tl[3], tl[5]));
-                vh[5] = __builtin_elementwise_fma(k4, th[1], __builtin_elementwise_fma(kn5, th[3], th[5]));
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const Con
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (nu == 4 && ch == CPS - 1 && more) {                   // hand-over into the other stage buffer from inside the MFMA block
-                    stage_store(smem + ((st + 1) & 1) * W24_STAGE);
+                    stage_store(smem + (BUF ^ 1) * W24_STAGE);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 const float4 bb = bq[ch & 1][nu];
@@ -291,6 +300,11 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const Con
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
+    };
+#pragma unroll 1
+    for (int st = 0; st < nstage; st += 2) {
+        stage(st, std::integral_constant<int, 0>{});
+        if (st + 1 < nstage) stage(st + 1, std::integral_constant<int, 1>{});
     }
 
     if (nb < NTILES) {            // block-uniform (ragged last channel block computes a duplicate that is never stored)
@@ -312,11 +326,7 @@ int cp_launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s)
                     (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
     if (!ok) return -1;
     const int smem = W24_SMEM_FLOATS * 4;
-    static CpLdsGuard guard;
-    if (smem > 64 * 1024) {
-        const hipError_t e = guard.ensure((const void*)conv3x3_wino24_kernel, smem);
-        if (e != hipSuccess) { cp_set_error("conv3x3_winograd24: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
-    }
+    static_assert(W24_SMEM_FLOATS * 4 <= 64 * 1024, "no dynamic-LDS attribute needed");
     W24Grid gd;
     gd.tilesX = cp_cdiv(a.W, 16); gd.tilesY = cp_cdiv(a.H, 16);
     gd.ntb = (a.Cout + 31) / 32;
