@@ -26,5 +26,5 @@ void cp_note_kernel(const char* fmt, ...)
     va_end(ap);
 }
 extern "C" const char* cp_last_kernel(void) { return g_kernel; }
-extern "C" int cp_abi_version(void) { return 3; }      // 2: plan handle (cp_plan_*), decode of any map size; 3: cp_dcn_desc.ksplit
+extern "C" int cp_abi_version(void) { return 4; }      // 2: plan handle (cp_plan_*), decode of any map size; 3: cp_dcn_desc.ksplit; 4: cp_dcn_desc.dg
 extern "C" const char* cp_target_arch(void) { return "gfx950"; }

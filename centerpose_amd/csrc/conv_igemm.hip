@@ -264,7 +264,7 @@ static int conv_args_from_desc(const cp_conv_desc* d, const float* const* src, c
     a.K = d->K; a.w = w; a.ldw = d->ldw; a.scale = scale; a.shift = shift;
     a.res = res; a.resLd = d->resLd; a.out = out; a.outLd = d->outLd; a.Cout = d->Cout;
     a.outNCHW = d->outNCHW; a.OH = d->OH; a.OW = d->OW; a.osy = d->osy; a.osx = d->osx; a.ooy = d->ooy; a.oox = d->oox;
-    a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1; a.ksplit = d->ksplit > 1 ? d->ksplit : 1; a.nsub = d->nsub > 1 ? d->nsub : 1;
+    a.act = d->act; a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dg = 1; a.dily = a.dilx = 1; a.ksplit = d->ksplit > 1 ? d->ksplit : 1; a.nsub = d->nsub > 1 ? d->nsub : 1;
     CP_CHECK_ARG(a.M > 0 && (long long)d->B * d->H * d->W < (1ll << 31), "conv2d: bad problem size");
     for (int i = 0; i < d->nsrc && !d->inNCHW; ++i)
         CP_CHECK_ARG((long long)d->B * d->H * d->W * d->srcLd[i] * 4 < (1ll << 32), "conv2d: source %d exceeds 32-bit byte offsets", i);

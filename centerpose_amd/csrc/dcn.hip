@@ -44,9 +44,12 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     static_assert(ASL >= 1, "BM too small for this gather width");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // records first, GEMM staging after; the NCHW epilogue reuses the whole region from the base
-    float4* s_w = reinterpret_cast<float4*>(smem);                 // [taps][BM] corner weights * mask
-    int* s_code = reinterpret_cast<int*>(s_w + DCN_MAX_TAPS * BM); // [taps][BM] base | dx<<29 | dy<<30
-    float* As0 = smem + DCN_MAX_TAPS * BM * 5;      // [2 buffers][A_FLOATS]
+    // dg = deformable groups (dcn_v2_im2col_cuda.cu:153,162-164: input channel c samples with the offsets / mask of group
+    // c / (C / dg)): one record set per group, record index (g * DCN_MAX_TAPS + tap) * BM + pixel
+    const int dg = a.dg;
+    float4* s_w = reinterpret_cast<float4*>(smem);                      // [dg][taps][BM] corner weights * mask
+    int* s_code = reinterpret_cast<int*>(s_w + dg * DCN_MAX_TAPS * BM); // [dg][taps][BM] base | dx<<29 | dy<<30
+    float* As0 = smem + dg * DCN_MAX_TAPS * BM * 5; // [2 buffers][A_FLOATS]
     float* Bs0 = As0 + 2 * T::A_FLOATS;             // [2 buffers][B_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -82,11 +85,13 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
         const int by = oy * a.sy - a.py, bx = ox * a.sx - a.px, bpix = b * a.H * a.W;
         const float fH = (float)a.H, fW = (float)a.W;
         const unsigned ld4 = (unsigned)ld >> 2;
+        for (int g = 0; g < dg; ++g) {                                     // (scalar loop; dg = 1 for every network layer)
+        const int og = g * ntap;                                           // group g: offsets at 2 * (og + t), mask at omMaskOff + og + t
         int t = tap0 + __builtin_amdgcn_readfirstlane(tid / BM);           // wave-uniform: BM is a multiple of the wave size
         int ky = t / a.kw, kx = t - ky * a.kw;                             // scalar
         for (; t < tap1; t += TS) {
-            const float offh = omp[2 * t], offw = omp[2 * t + 1];
-            float mk = omp[a.omMaskOff + t];
+            const float offh = omp[2 * (og + t)], offw = omp[2 * (og + t) + 1];
+            float mk = omp[a.omMaskOff + og + t];
             if (a.omSigmoid) mk = __builtin_amdgcn_rcpf(1.0f + __expf(-mk));
             const float h_im = (float)(by + ky * a.dily) + offh;
             const float w_im = (float)(bx + kx * a.dilx) + offw;
@@ -102,12 +107,13 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
             const float top = (t_ok ? hh : lh) * mv, bot = (dyb ? lh : 0.f) * mv;
             const float lft = l_ok ? hw : lw, rgt = dxb ? lw : 0.f;
             const int yl = min(max(h_low, 0), a.H - 1), xl = min(max(w_low, 0), a.W - 1);      // in range even for an invalid sample
-            s_w[t * BM + pl] = make_float4(top * lft, top * rgt, bot * lft, bot * rgt);
+            s_w[(g * DCN_MAX_TAPS + t) * BM + pl] = make_float4(top * lft, top * rgt, bot * lft, bot * rgt);
             // base = byte offset of the clamped top-left corner in 16-byte units (< 2^28: the launcher checks 32-bit byte offsets): the
             // multiply by the pixel stride is done HERE, once per record, not once per (tap, k-walk) in the main loop
-            s_code[t * BM + pl] = (int)((unsigned)(bpix + yl * a.W + xl) * ld4) | ((dxb ? 1 : 0) << 29) | ((dyb ? 1 : 0) << 30);
+            s_code[(g * DCN_MAX_TAPS + t) * BM + pl] = (int)((unsigned)(bpix + yl * a.W + xl) * ld4) | ((dxb ? 1 : 0) << 29) | ((dyb ? 1 : 0) << 30);
             kx += TS;
             while (kx >= a.kw) { kx -= a.kw; ++ky; }
+        }
         }
     }
 
@@ -124,6 +130,8 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     float4 br[T::B_SLOTS];
     float4 c00[ASL], c01[ASL], c10[ASL], c11[ASL], wq[ASL];
     int tap = tap0, cl = 0;
+    const int cpg = C / dg;                         // channels per deformable group (a multiple of the 16-channel k-step)
+    int gnext = 0, grec = 0;                        // first channel of the next group inside the tap; record row of the current group
     __syncthreads();
 
     // Corner byte offsets and blend weights are per (tap, pixel): computed at the first k-step of a tap and reused by its
@@ -132,12 +140,14 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     const unsigned pixb = (unsigned)ld * 4u, rowb = (unsigned)a.W * pixb;
     unsigned o00[ASL], o01[ASL], o10[ASL], o11[ASL];
     auto load_a = [&]() __attribute__((always_inline)) {
-        if (cl == 0) {
+        if (cl == gnext) {                          // first k-step of a (tap, group): dg = 1 -> once per tap
+            grec = (cl == 0 ? 0 : grec + DCN_MAX_TAPS) ;
+            gnext = cl + cpg;
 #pragma unroll
             for (int s = 0; s < ASL; ++s) {
                 const int pl = tid / QL + s * PPP;
-                const int code = s_code[tap * BM + pl];
-                wq[s] = s_w[tap * BM + pl];
+                const int code = s_code[(grec + tap) * BM + pl];
+                wq[s] = s_w[(grec + tap) * BM + pl];
                 o00[s] = (((unsigned)code & 0x0FFFFFFFu) << 4) + (unsigned)q * 16u;
                 o01[s] = o00[s] + (((unsigned)code >> 29) & 1u) * pixb;
                 o10[s] = o00[s] + (((unsigned)code >> 30) & 1u) * rowb;
@@ -153,7 +163,7 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
             c11[s] = ig_ldg4(reinterpret_cast<const float*>(xs + o11[s]));
         }
     };
-    auto advance = [&]() __attribute__((always_inline)) { cl += IG_BK; if (cl >= C) { cl = 0; ++tap; } };
+    auto advance = [&]() __attribute__((always_inline)) { cl += IG_BK; if (cl >= C) { cl = 0; gnext = 0; ++tap; } };
     auto store_a = [&](float* As) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < ASL; ++s) {
@@ -224,7 +234,9 @@ static int launch_dcn(const ConvArgs& a, hipStream_t s)
     auto kern = dcn_igemm_kernel<BM, BN, WAVES_M, WAVES_N, MF>;
     if (a.srcC[0] % IG_BK != 0) { cp_set_error("dcn: C=%d is not a multiple of %d", a.srcC[0], IG_BK); return 1; }
     if (a.ldw % BN != 0) { cp_set_error("dcn: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
-    const int main_bytes = T::MAIN_BYTES + DCN_MAX_TAPS * BM * 20;
+    if ((a.srcC[0] / a.dg) % IG_BK != 0) { cp_set_error("dcn: C / deformable_group = %d is not a multiple of %d", a.srcC[0] / a.dg, IG_BK); return 1; }
+    const int main_bytes = T::MAIN_BYTES + a.dg * DCN_MAX_TAPS * BM * 20;
+    if (main_bytes > 160 * 1024) { cp_set_error("dcn: deformable_group = %d needs %d B of LDS", a.dg, main_bytes); return 1; }
     const int epi = a.outNCHW ? T::EPI_BYTES : T::EPV_BYTES;
     const int smem = epi > main_bytes ? epi : main_bytes;
     static CpLdsGuard guard;
@@ -248,6 +260,8 @@ struct cp_dcn_desc {
     int tile;
     int ksplit;                // 0 / 1: whole K in one block.  S > 1: split-K over the taps -- `out` is a workspace [S][M][outLd] of raw
                                // partial sums (pass scale = 1, shift = 0, act = none, NHWC, outLd = ldw); cp_splitk_reduce_f32 finishes
+    int dg;                    // 0 / 1: one deformable group.  G > 1: input channel c uses the offsets / mask of group c / (C / G);
+                               // om channels 2 * (g * kh*kw + k) = dy, + 1 = dx, 2 * G * kh*kw + g * kh*kw + k = mask; (C / G) % 16 == 0
 };
 
 extern "C" int cp_sizeof_dcn_desc(void) { return (int)sizeof(cp_dcn_desc); }
@@ -260,7 +274,9 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
     CP_CHECK_ARG(d->C % 16 == 0 && d->srcLd % 4 == 0 && d->srcLd >= d->C, "dcn_v2: C%%16==0, ld%%4==0 required");
     CP_CHECK_ARG(d->K == d->kh * d->kw * d->C, "dcn_v2: K=%d != kh*kw*C", d->K);
     CP_CHECK_ARG(d->ldw % 16 == 0 && d->ldw >= d->Cout, "dcn_v2: ldw=%d Cout=%d", d->ldw, d->Cout);
-    CP_CHECK_ARG(d->omLd >= 3 * d->kh * d->kw, "dcn_v2: omLd=%d too small", d->omLd);
+    const int dgv = d->dg > 1 ? d->dg : 1;
+    CP_CHECK_ARG(d->C % dgv == 0 && (d->C / dgv) % 16 == 0, "dcn_v2: C=%d must split into %d deformable groups of a multiple of 16 channels", d->C, dgv);
+    CP_CHECK_ARG(d->omLd >= 3 * dgv * d->kh * d->kw, "dcn_v2: omLd=%d too small", d->omLd);
     CP_CHECK_ARG((long long)d->B * d->H * d->W < (1ll << 29) && (long long)d->B * d->H * d->W * d->srcLd * 4 < (1ll << 32),
                  "dcn_v2: input too large (pixel index 29 bits, byte offsets 32 bits)");
     ConvArgs a;
@@ -271,7 +287,7 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
     a.K = d->K; a.w = w; a.ldw = d->ldw; a.scale = scale; a.shift = shift; a.res = nullptr; a.resLd = 0;
     a.out = out; a.outLd = d->outLd; a.Cout = d->Cout; a.outNCHW = d->outNCHW;
     a.OH = d->Ho; a.OW = d->Wo; a.osy = a.osx = 1; a.ooy = a.oox = 0; a.act = d->act;
-    a.om = om; a.omLd = d->omLd; a.omMaskOff = 2 * d->kh * d->kw; a.omSigmoid = d->omSigmoid;
+    a.om = om; a.omLd = d->omLd; a.omMaskOff = 2 * dgv * d->kh * d->kw; a.omSigmoid = d->omSigmoid; a.dg = dgv;
     a.dily = d->dily; a.dilx = d->dilx; a.nsub = 1;
     a.ksplit = d->ksplit > 1 ? d->ksplit : 1;
     CP_CHECK_ARG(a.ksplit <= d->kh * d->kw, "dcn_v2: ksplit=%d exceeds the %d taps", a.ksplit, d->kh * d->kw);

@@ -58,6 +58,7 @@ struct ConvArgs {
     int dily, dilx;           // dilation (DCNv2 drop-in only; plain convs are dilation 1)
     int ksplit;               // DCNv2 only: > 1 = split-K over the taps: block (tile, split s) accumulates taps [s*T/S, (s+1)*T/S) and
                               // stores the RAW partial sums to out + s*M*outLd (cp_splitk_reduce_f32 sums them in a fixed order)
+    int dg;                   // DCNv2 only: deformable groups (>= 1)
     int nsub;                 // 1, or 4: the four sub-pixel 2x2 convs of a k4/s2/p1 ConvTranspose2d in ONE launch (generic kernel only):
                               // sub g = py*2+px uses weights w + g*ldw*K, pad (py0 - py, px0 - px) and output phase (ooy + py, oox + px)
 };

@@ -6,10 +6,16 @@
 //     dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group) -> Tensor
 //         identical 14-argument signature (src/dcn_v2.h:9-23); fp32 contiguous NCHW HIP tensors in, a NEW NCHW tensor out
 //         (at::empty, dcn_v2_cuda.cu:91); CPU tensors raise like AT_ERROR("Not implemented on the CPU") (cpu/dcn_v2_cpu.cpp:7-24)
-//     multi_pose_decode(heat, wh, kps, reg?, hm_hp?, hp_offset?, K) -> Tensor[B,K,5+3J]        (lib/models/decode.py:235-308)
+//         any deformable_group (dcn_v2_im2col_cuda.cu:153,162-164); packed weights cached on (data_ptr, _version)
+//     multi_pose_decode(heat, wh, kps, reg?, hm_hp?, hp_offset?, K, return_indices=False) -> Tensor[B,K,5+3J]  (lib/models/decode.py:235-308)
+//     plan_create_from_state_dict(arch, state_dict, B, H, W, head_conv=None, use_graph=True) -> handle       
 //     plan_create(path, use_graph) -> handle; plan_forward(handle, images) -> 6 tensors; plan_process(handle, images, K) -> dets;
 //     plan_destroy(handle)                                                                      (lib/models/model.py:57-59)
 // Kernels are enqueued on the current HIP stream of the input's device; nothing synchronises the host.
+#include <map>
+#include <mutex>
+#include <tuple>
+
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
 
@@ -35,6 +41,46 @@ at::Tensor nhwc_from_nchw(const at::Tensor& x, int Cpad, int c_off, at::Tensor o
     return out;
 }
 
+// Kernel-side constants of one (weight, bias) pair: packed [ldw][kh*kw*Cp] weights (k = (ky*kw + kx)*Cp + c, every deformable group
+// padded to a multiple of 16 channels), scale = 1, shift = bias.  The reference's DCN module passes the same parameters on every
+// forward (DCNv2/dcn_v2.py:117-127); re-packing them per call cost more than the convolution, so the result is cached
+// on (data_ptr, _version) of both tensors.  An in-place update of a parameter bumps its version: the entry is rebuilt.
+struct PackedDcn {
+    at::Tensor wp, scale, shift;
+    int ldw, Cp;
+};
+struct PackedKey {
+    const void *w, *b;
+    int64_t wv, bv;
+    int dg, dev;
+    bool operator<(const PackedKey& o) const { return std::tie(w, b, wv, bv, dg, dev) < std::tie(o.w, o.b, o.wv, o.bv, o.dg, o.dev); }
+};
+std::map<PackedKey, PackedDcn> g_packed;
+std::mutex g_packed_mu;
+
+PackedDcn packed_dcn_weights(const at::Tensor& weight, const at::Tensor& bias, int dg)
+{
+    const PackedKey key{weight.data_ptr(), bias.data_ptr(), (int64_t)weight._version(), (int64_t)bias._version(), dg, (int)weight.get_device()};
+    std::lock_guard<std::mutex> lock(g_packed_mu);
+    auto it = g_packed.find(key);
+    if (it != g_packed.end()) return it->second;
+    const int Co = weight.size(0), C = weight.size(1), kh = weight.size(2), kw = weight.size(3), kk = kh * kw;
+    const int cpg = C / dg, cpgp = (cpg + 15) / 16 * 16, Cp = dg * cpgp, Cop = Co > 17 ? Co : 17;
+    const auto opt = weight.options();
+    PackedDcn r;
+    r.Cp = Cp;
+    r.ldw = Cop <= 32 ? 32 : (Cop + 63) / 64 * 64;          // Cout padded to the kernel's N tile
+    r.wp = at::zeros({r.ldw, kk * Cp}, opt);
+    r.wp.view({r.ldw, kk, dg, cpgp}).slice(0, 0, Co).slice(3, 0, cpg).copy_(weight.reshape({Co, dg, cpg, kk}).permute({0, 3, 1, 2}));
+    r.scale = at::zeros({r.ldw}, opt);
+    r.shift = at::zeros({r.ldw}, opt);
+    r.scale.slice(0, 0, Co).fill_(1.0f);
+    r.shift.slice(0, 0, Co).copy_(bias);
+    if (g_packed.size() >= 64) g_packed.clear();
+    g_packed[key] = r;
+    return r;
+}
+
 at::Tensor dcn_v2_forward(const at::Tensor& input, const at::Tensor& weight, const at::Tensor& bias, const at::Tensor& offset,
                           const at::Tensor& mask, int kernel_h, int kernel_w, int stride_h, int stride_w, int pad_h, int pad_w,
                           int dilation_h, int dilation_w, int deformable_group)
@@ -47,34 +93,37 @@ at::Tensor dcn_v2_forward(const at::Tensor& input, const at::Tensor& weight, con
     TORCH_CHECK(weight.size(2) == kernel_h && weight.size(3) == kernel_w, "Input shape and kernel shape wont match: (", kernel_h,
                 " x ", kernel_w, " vs ", weight.size(2), " x ", weight.size(3), ").");                                   // :77-78
     TORCH_CHECK(stride_h == stride_w && pad_h == pad_w && dilation_h == dilation_w, "square stride / pad / dilation only");
-    TORCH_CHECK(deformable_group == 1, "deformable_group != 1 is not supported (the reference only uses 1, pose_dla_dcn.py:343)");
+    const int dg = deformable_group;
+    TORCH_CHECK(dg >= 1 && C % dg == 0, "channels (", C, ") must be divisible by deformable_group (", dg, ")");
     const int kk = kernel_h * kernel_w;
     TORCH_CHECK(kk <= 9, "at most 9 taps");
     const int Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) / stride_h + 1;
     const int Wo = (W + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) / stride_w + 1;
-    TORCH_CHECK(offset.size(0) == B && offset.size(1) == 2 * kk && offset.size(2) == Ho && offset.size(3) == Wo &&
-                mask.size(0) == B && mask.size(1) == kk && mask.size(2) == Ho && mask.size(3) == Wo, "offset / mask shape");
+    // dcn_v2_im2col_cuda.cu:162-164: group g's offsets are channels g*2*kk .., its masks channels g*kk ..
+    TORCH_CHECK(offset.size(0) == B && offset.size(1) == 2 * dg * kk && offset.size(2) == Ho && offset.size(3) == Wo &&
+                mask.size(0) == B && mask.size(1) == dg * kk && mask.size(2) == Ho && mask.size(3) == Wo, "offset / mask shape");
     const auto opt = input.options();
-    const int Cp = (C + 15) / 16 * 16, omld = (3 * kk + 3) / 4 * 4, Cop = Co > 17 ? Co : 17;
+    const PackedDcn pk = packed_dcn_weights(weight, bias, dg);
+    const int cpg = C / dg, cpgp = pk.Cp / dg, Cp = pk.Cp, omld = (3 * dg * kk + 3) / 4 * 4;
     // NHWC staging (the fused network plan keeps NHWC end to end; this entry exists so that the reference's own DCN module runs)
-    at::Tensor x = nhwc_from_nchw(input, Cp, 0, Cp != C ? at::zeros({B, H, W, Cp}, opt) : at::empty({B, H, W, Cp}, opt));
-    at::Tensor om = at::zeros({B, Ho, Wo, omld}, opt);
-    nhwc_from_nchw(offset, omld, 0, om);
-    nhwc_from_nchw(mask, omld, 2 * kk, om);
-    // packed weights [ldw][kh*kw*Cp], k = (ky*kw + kx)*Cp + c; ldw = Cout padded to the kernel's N tile; bias as `shift`, scale 1
-    const int ldw = Cop <= 32 ? 32 : (Cop + 63) / 64 * 64;
-    at::Tensor wp = at::zeros({ldw, kk * Cp}, opt);
-    wp.view({ldw, kk, Cp}).slice(0, 0, Co).slice(2, 0, C).copy_(weight.permute({0, 2, 3, 1}).reshape({Co, kk, C}));
-    at::Tensor scale = at::zeros({ldw}, opt), shift = at::zeros({ldw}, opt);
-    scale.slice(0, 0, Co).fill_(1.0f);
-    shift.slice(0, 0, Co).copy_(bias);
+    at::Tensor x;
+    if (cpgp == cpg) x = nhwc_from_nchw(input, Cp, 0, at::empty({B, H, W, Cp}, opt));
+    else {                      // every group padded to a multiple of 16 channels: layout staging with torch views, not compute
+        x = at::zeros({B, H, W, dg, cpgp}, opt);
+        x.slice(4, 0, cpg).copy_(input.reshape({B, dg, cpg, H, W}).permute({0, 3, 4, 1, 2}));
+        x = x.view({B, H, W, Cp});
+    }
+    at::Tensor om = (3 * dg * kk == omld) ? at::empty({B, Ho, Wo, omld}, opt) : at::zeros({B, Ho, Wo, omld}, opt);
+    nhwc_from_nchw(offset, omld, 0, om);                    // channel 2 * (g * kk + k) (+ 1): the reference's own order
+    nhwc_from_nchw(mask, omld, 2 * dg * kk, om);
     at::Tensor out = at::empty({B, Co, Ho, Wo}, opt);                                               // new tensor, dcn_v2_cuda.cu:91
     cp_dcn_desc d = {};
     d.B = B; d.H = H; d.W = W; d.C = Cp; d.srcLd = Cp; d.Ho = Ho; d.Wo = Wo;
     d.kh = kernel_h; d.kw = kernel_w; d.sy = stride_h; d.sx = stride_w; d.py = pad_h; d.px = pad_w; d.dily = dilation_h; d.dilx = dilation_w;
-    d.K = kk * Cp; d.ldw = ldw; d.Cout = Co; d.omLd = omld; d.omSigmoid = 0; d.outLd = 0; d.outNCHW = 1; d.act = CP_ACT_NONE; d.tile = 0; d.ksplit = 0;
-    CP_CALL(cp_dcn_v2_f32(&d, x.data_ptr<float>(), om.data_ptr<float>(), wp.data_ptr<float>(), scale.data_ptr<float>(),
-                          shift.data_ptr<float>(), out.data_ptr<float>(), cur_stream(input)), "cp_dcn_v2_f32");
+    d.K = kk * Cp; d.ldw = pk.ldw; d.Cout = Co; d.omLd = omld; d.omSigmoid = 0; d.outLd = 0; d.outNCHW = 1; d.act = CP_ACT_NONE; d.tile = 0; d.ksplit = 0;
+    d.dg = dg;
+    CP_CALL(cp_dcn_v2_f32(&d, x.data_ptr<float>(), om.data_ptr<float>(), pk.wp.data_ptr<float>(), pk.scale.data_ptr<float>(),
+                          pk.shift.data_ptr<float>(), out.data_ptr<float>(), cur_stream(input)), "cp_dcn_v2_f32");
     return out;
 }
 
@@ -84,8 +133,10 @@ std::vector<at::Tensor> dcn_v2_backward(const at::Tensor&, const at::Tensor&, co
     TORCH_CHECK(false, "dcn_v2_backward: training is out of scope of the MI355X inference hot path");
 }
 
-at::Tensor multi_pose_decode(const at::Tensor& heat, const at::Tensor& wh, const at::Tensor& kps, const c10::optional<at::Tensor>& reg,
-                             const c10::optional<at::Tensor>& hm_hp, const c10::optional<at::Tensor>& hp_offset, int K)
+// return_indices: also (inds [B,K] int32 = centre indices, hm_inds [B,J,K] int32 = joint-candidate indices, scores [B,1+J,K]) --
+// what the reference's _topk / _topk_channel return (decode.py:87-115) and the bit-exact index checks compare
+py::object multi_pose_decode(const at::Tensor& heat, const at::Tensor& wh, const at::Tensor& kps, const c10::optional<at::Tensor>& reg,
+                             const c10::optional<at::Tensor>& hm_hp, const c10::optional<at::Tensor>& hp_offset, int K, bool return_indices)
 {
     TORCH_CHECK(hm_hp.has_value(), "name 'hm_score' is not defined (hm_hp is mandatory: lib/models/decode.py:265,307)");
     check_gpu_f32(heat, "heat"); check_gpu_f32(wh, "wh"); check_gpu_f32(kps, "kps"); check_gpu_f32(*hm_hp, "hm_hp");
@@ -95,19 +146,34 @@ at::Tensor multi_pose_decode(const at::Tensor& heat, const at::Tensor& wh, const
     if (reg.has_value()) { check_gpu_f32(*reg, "reg"); r = reg->contiguous(); }
     if (hp_offset.has_value()) { check_gpu_f32(*hp_offset, "hp_offset"); ho = hp_offset->contiguous(); }
     at::Tensor dets = at::empty({B, K, 5 + 3 * J}, heat.options());
-    if (B == 0) return dets;
     at::Tensor ws = at::empty({B, 1 + J, K}, heat.options()), wi = at::empty({B, 1 + J, K}, heat.options().dtype(at::kInt));
-    CP_CALL(cp_multi_pose_decode_f32(h.data_ptr<float>(), w.data_ptr<float>(), k.data_ptr<float>(), r.defined() ? r.data_ptr<float>() : nullptr,
-                                     hp.data_ptr<float>(), ho.defined() ? ho.data_ptr<float>() : nullptr, B, cat, J, H, W, K,
-                                     dets.data_ptr<float>(), ws.data_ptr<float>(), wi.data_ptr<int>(), cur_stream(heat)),
-            "cp_multi_pose_decode_f32");
-    return dets;
+    if (B > 0)
+        CP_CALL(cp_multi_pose_decode_f32(h.data_ptr<float>(), w.data_ptr<float>(), k.data_ptr<float>(), r.defined() ? r.data_ptr<float>() : nullptr,
+                                         hp.data_ptr<float>(), ho.defined() ? ho.data_ptr<float>() : nullptr, B, cat, J, H, W, K,
+                                         dets.data_ptr<float>(), ws.data_ptr<float>(), wi.data_ptr<int>(), cur_stream(heat)),
+                "cp_multi_pose_decode_f32");
+    if (!return_indices) return py::cast(dets);
+    return py::make_tuple(dets, wi.select(1, 0), wi.slice(1, 1, 1 + J), ws);
 }
 
 int64_t plan_create(const std::string& path, bool use_graph)
 {
     cp_plan* p = nullptr;
     CP_CALL(cp_plan_load(path.c_str(), use_graph ? 1 : 0, &p), "cp_plan_load");
+    return reinterpret_cast<int64_t>(p);
+}
+
+// plan_create(arch, state_dict tensors, B, H, W).  The checkpoint -> plan compiler (BN folding, weight packing,
+// Winograd transforms, launch schedule) is host orchestration and stays Python (centerpose_amd.plan.compile_state_dict); its output is
+// the same flat plan blob a file would hold, handed to cp_plan_create without touching the disk.  state_dict: the reference's
+// checkpoint["state_dict"] (lib/models/model.py:67-120; a leading "module." is stripped); head_conv: cfg.MODEL.HEAD_CONV or None.
+int64_t plan_create_from_state_dict(const std::string& arch, const py::dict& state_dict, int B, int H, int W, const py::object& head_conv,
+                                    bool use_graph)
+{
+    py::object compile = py::module_::import("centerpose_amd.plan").attr("compile_state_dict");
+    const std::string blob = py::bytes(compile(arch, state_dict, B, H, W, head_conv));
+    cp_plan* p = nullptr;
+    CP_CALL(cp_plan_create(blob.data(), blob.size(), use_graph ? 1 : 0, &p), "cp_plan_create");
     return reinterpret_cast<int64_t>(p);
 }
 
@@ -159,8 +225,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("dcn_v2_forward", &dcn_v2_forward, "dcn_v2_forward");       // DCNv2/src/vision.cpp:6
     m.def("dcn_v2_backward", &dcn_v2_backward, "dcn_v2_backward");    // :7 (raises: inference only)
     m.def("multi_pose_decode", &multi_pose_decode, py::arg("heat"), py::arg("wh"), py::arg("kps"), py::arg("reg") = py::none(),
-          py::arg("hm_hp") = py::none(), py::arg("hp_offset") = py::none(), py::arg("K") = 100);
+          py::arg("hm_hp") = py::none(), py::arg("hp_offset") = py::none(), py::arg("K") = 100, py::arg("return_indices") = false);
     m.def("plan_create", &plan_create, py::arg("path"), py::arg("use_graph") = true);
+    m.def("plan_create_from_state_dict", &plan_create_from_state_dict, py::arg("arch"), py::arg("state_dict"), py::arg("B"), py::arg("H"),
+          py::arg("W"), py::arg("head_conv") = py::none(), py::arg("use_graph") = true);
     m.def("plan_forward", &plan_forward);
     m.def("plan_process", &plan_process, py::arg("handle"), py::arg("images"), py::arg("K") = 100);
     m.def("plan_destroy", &plan_destroy);

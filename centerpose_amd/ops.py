@@ -25,7 +25,7 @@ class ConvDesc(ctypes.Structure):
 class DcnDesc(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ("B", "H", "W", "C", "srcLd", "Ho", "Wo", "kh", "kw", "sy", "sx", "py", "px",
                                             "dily", "dilx", "K", "ldw", "Cout", "omLd", "omSigmoid", "outLd",
-                                            "outNCHW", "act", "tile", "ksplit")]
+                                            "outNCHW", "act", "tile", "ksplit", "dg")]
 
 
 def round_up(x, m):
@@ -317,8 +317,9 @@ def dcn_v2(x, om, wp, scale, shift, out, **kw):
 
 
 def dcn_v2_launch(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, pad=1, dil=1, om_sigmoid=True,
-                  act=ACT_NONE, out_nchw=False, tile=0, ksplit=0):
-    """Fused DCNv2: x NHWC [B,H,W,C]; om NHWC [B,Ho,Wo,>=3*kh*kw] (dy,dx pairs then mask).
+                  act=ACT_NONE, out_nchw=False, tile=0, ksplit=0, dg=1):
+    """Fused DCNv2: x NHWC [B,H,W,C]; om NHWC [B,Ho,Wo,>=3*dg*kh*kw] (per group the dy,dx pairs; then per group the masks).
+    dg: deformable groups (channel c uses group c // (C // dg); (C // dg) % 16 == 0).
     ksplit = S > 1: split-K over the taps; `out` is then the workspace [S, B*Ho*Wo, ldw] of raw partial sums (scale = ones,
     shift = zeros, act none, cout = ldw) and `splitk_reduce_launch` finishes the layer."""
     B, H, W, C = x.shape
@@ -331,7 +332,7 @@ def dcn_v2_launch(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, p
     d.K, d.ldw, d.Cout = wp.shape[1], wp.shape[0], cout
     d.omLd, d.omSigmoid = _ld(om), 1 if om_sigmoid else 0
     d.outNCHW = 1 if out_nchw else 0
-    d.act, d.tile, d.ksplit = act, tile, ksplit
+    d.act, d.tile, d.ksplit, d.dg = act, tile, ksplit, dg
     if ksplit > 1:
         assert tuple(out.shape) == (ksplit, B * Ho * Wo, wp.shape[0]) and out.is_contiguous() and cout == wp.shape[0] and act == ACT_NONE
         d.outLd = wp.shape[0]

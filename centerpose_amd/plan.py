@@ -147,8 +147,8 @@ def serialize(launches, meta, inp, outputs, abi, streams=None):
     return bytes(out)
 
 
-def save_plan(engine, path, deterministic=False):
-    """Write `engine`'s compiled plan (packed constants + launch schedule) to `path`.  The schedule is the two-stream one, so the
+def plan_blob(engine, deterministic=False):
+    """`engine`'s compiled plan (packed constants + launch schedule) as bytes.  The schedule is the two-stream one, so the
     C runtime replays what Python replays: the engine's own if it has one; otherwise one is made here -- applied to the engine
     when it has not captured yet (it will then capture the same order), computed on the side when a graph already exists (an
     engine captured with CP_STREAMS=1 / CP_SCHED=0 keeps its launch order, `stream_of_launch` and profile indices: ADVICE r2)."""
@@ -173,10 +173,26 @@ def save_plan(engine, path, deterministic=False):
             order, assign, _ = engine.plan_schedule(None)
             launches, streams = [engine.launches[i] for i in order], [assign[i] for i in order]
     meta = {"arch": engine.arch, "flops_per_image": int(engine.flops_per_image)}
-    blob = serialize(launches, meta, engine.input, engine.outputs, int(_lib.lib().cp_abi_version()), streams)
+    return serialize(launches, meta, engine.input, engine.outputs, int(_lib.lib().cp_abi_version()), streams)
+
+
+def save_plan(engine, path, deterministic=False):
+    """Write `engine`'s compiled plan to `path` (`plan_blob`); returns the file size."""
+    blob = plan_blob(engine, deterministic)
     with open(path, "wb") as f:
         f.write(blob)
     return len(blob)
+
+
+def compile_state_dict(arch, state_dict, B, H, W, head_conv=None):
+    """checkpoint tensors -> plan bytes (plan_create(arch, state_dict tensors, B, H, W)): what
+    `_ext.plan_create_from_state_dict` hands to cp_plan_create.  state_dict: the reference's checkpoint["state_dict"]
+    (lib/models/model.py:67-120; "module." prefixes are stripped); hm / hm_hp sigmoided as MultiPoseDetector.process does;
+    deterministic model schedule (no timing passes)."""
+    from . import engine as _engine
+    sd = {k: (v if torch.is_tensor(v) else torch.as_tensor(v)) for k, v in dict(state_dict).items()}
+    eng = _engine.Engine(arch, sd, int(B), int(H), int(W), head_conv=head_conv, sigmoid_heads=("hm", "hm_hp"), use_graph=False)
+    return plan_blob(eng, deterministic=True)
 
 
 class _Reader:

@@ -94,7 +94,8 @@ int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const float* u, 
  * src/cuda/dcn_v2_im2col_cuda.cu:25-54,125-195) plus the BN + ReLU of DeformConv (pose_dla_dcn.py:345-348).
  * x: NHWC [B,H,W,srcLd]; om: NHWC [B,Ho,Wo,omLd] with ch 2k = dy_k, 2k+1 = dx_k, 2*kh*kw + k = mask_k
  * (logits if omSigmoid, as produced by conv_offset_mask, dcn_v2.py:117-121; already-sigmoided otherwise);
- * w: [ldw][kh*kw*C]; deformable_group == 1 (the only value the reference uses). */
+ * w: [ldw][kh*kw*C]; deformable groups: `dg` below (the reference's models only use 1, pose_dla_dcn.py:343; the interface
+ * implements any, dcn_v2_im2col_cuda.cu:153,162-164). */
 typedef struct cp_dcn_desc {
     int B, H, W, C, srcLd;
     int Ho, Wo;
@@ -106,6 +107,9 @@ typedef struct cp_dcn_desc {
     int ksplit;     /* 0 / 1: none.  S > 1: split-K over the taps for small-M layers: `out` is a workspace [S][B*Ho*Wo][ldw] that receives
                      * the raw partial sums (scale = ones, shift = zeros, act = CP_ACT_NONE, NHWC, outLd = Cout = ldw);
                      * cp_splitk_reduce_f32 sums the S slices in a fixed order (deterministic) and applies scale / shift / act */
+    int dg;         /* 0 / 1: one deformable group.  G > 1: input channel c samples with the offsets / mask of group g = c / (C / G)
+                     * ((C / G) % 16 == 0): om channel 2 * (g * kh*kw + k) = dy, + 1 = dx, 2 * G * kh*kw + g * kh*kw + k = mask;
+                     * omLd >= 3 * G * kh*kw */
 } cp_dcn_desc;
 int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* om, const float* w, const float* scale,
                   const float* shift, float* out, void* stream);

@@ -74,7 +74,8 @@ def test_torch_extension_module_ext(lib):
     (the reference has no CPU implementation either: cpu/dcn_v2_cpu.cpp:7-24)."""
     import torch
     from centerpose_amd import _ext
-    for n in ("dcn_v2_forward", "dcn_v2_backward", "multi_pose_decode", "plan_create", "plan_forward", "plan_process", "plan_destroy"):
+    for n in ("dcn_v2_forward", "dcn_v2_backward", "multi_pose_decode", "plan_create", "plan_create_from_state_dict", "plan_forward",
+              "plan_process", "plan_destroy"):
         assert callable(getattr(_ext, n))
     z = torch.zeros
     with pytest.raises(RuntimeError, match="GPU"):

@@ -391,6 +391,99 @@ def test_pybind_ext_dcn_v2_forward(C, Co, k, s, p, d):
         _ext.dcn_v2_backward(*t, t[0], k, k, s, s, p, p, d, d, 1)
 
 
+@pytest.mark.parametrize("C,Co,dg,k,s,p,d", [(32, 64, 2, 3, 1, 1, 1), (64, 64, 4, 3, 1, 1, 1), (96, 128, 2, 3, 2, 1, 1), (12, 7, 3, 3, 1, 2, 2),
+                                             (20, 40, 2, 1, 1, 0, 1), (64, 32, 1, 3, 1, 1, 1)])
+@pytest.mark.parametrize("face", ["python", "pybind"])
+def test_dcn_v2_forward_deformable_groups(C, Co, dg, k, s, p, d, face):
+    """deformable_group > 1 through both faces of the reference FFI (the one argument of the 14 that used to raise).
+    Reference semantics dcn_v2_im2col_cuda.cu:153,162-164: channel c samples with group c // (C // dg); offset channels
+    [g*2*kk, (g+1)*2*kk), mask channels [g*kk, (g+1)*kk).  Oracle: oracle/dcn_ref.c (implements dg).  Channel counts per group that
+    are not multiples of 16 (12 / 3 = 4, 20 / 2 = 10) exercise the per-group padding of the wrappers."""
+    from oracle import dcn as odcn
+    if face == "python":
+        from centerpose_amd import dcn_v2_ext as ext
+    else:
+        from centerpose_amd import _ext as ext
+    r = np.random.RandomState(C * 3 + dg)
+    B, H, W = 2, 10, 13
+    Ho = (H + 2 * p - (d * (k - 1) + 1)) // s + 1
+    Wo = (W + 2 * p - (d * (k - 1) + 1)) // s + 1
+    x = r.randn(B, C, H, W).astype(np.float32)
+    w = (r.randn(Co, C, k, k) * 0.2).astype(np.float32)
+    b = r.randn(Co).astype(np.float32)
+    off = (r.randn(B, 2 * dg * k * k, Ho, Wo) * 2.5).astype(np.float32)
+    off[0, :, 0, 0] = 3 * H                     # far out of range in every group
+    off[-1, 0::2, 1, 1] = -1.0                  # on the boundary rule
+    m = r.rand(B, dg * k * k, Ho, Wo).astype(np.float32)
+    ref = odcn.dcn_v2_forward_c(x, w, b, off, m, k, k, s, s, p, p, d, d, dg)
+    if dg > 1:                                  # the groups really differ: group 0's offsets for everyone is another answer
+        off1 = np.tile(off[:, :2 * k * k], (1, dg, 1, 1))
+        assert np.abs(odcn.dcn_v2_forward_c(x, w, b, off1, m, k, k, s, s, p, p, d, d, dg) - ref).max() > 1e-2
+    t = [torch.from_numpy(a).cuda() for a in (x, w, b, off, m)]
+    out = ext.dcn_v2_forward(*t, k, k, s, s, p, p, d, d, dg)
+    assert out.shape == ref.shape and out.is_cuda
+    _close(out, torch.from_numpy(ref), 1e-4)
+    with pytest.raises(RuntimeError):
+        ext.dcn_v2_forward(*t, k, k, s, s, p, p, d, d, dg + 7 if C % (dg + 7) else C + 1)      # C not divisible by the group count
+
+
+@pytest.mark.parametrize("face", ["python", "pybind"])
+def test_dcn_v2_forward_weight_cache_follows_parameter_updates(face):
+    """The ext faces cache the packed weights on (data_ptr, _version) of weight and bias: a second call reuses
+    them, an IN-PLACE update of either parameter (what an optimizer step or load_state_dict does) must be seen."""
+    from oracle import dcn as odcn
+    if face == "python":
+        from centerpose_amd import dcn_v2_ext as ext
+    else:
+        from centerpose_amd import _ext as ext
+    r = np.random.RandomState(3)
+    x, off, m = r.randn(1, 32, 8, 8).astype(np.float32), r.randn(1, 18, 8, 8).astype(np.float32), r.rand(1, 9, 8, 8).astype(np.float32)
+    w = torch.from_numpy((r.randn(32, 32, 3, 3) * 0.2).astype(np.float32)).cuda()
+    b = torch.from_numpy(r.randn(32).astype(np.float32)).cuda()
+    t = [torch.from_numpy(a).cuda() for a in (x, off, m)]
+    call = lambda: ext.dcn_v2_forward(t[0], w, b, t[1], t[2], 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    o1, o2 = call(), call()
+    assert torch.equal(o1, o2)
+    _close(o1, torch.from_numpy(odcn.dcn_v2_forward_c(x, w.cpu().numpy(), b.cpu().numpy(), off, m)), 1e-4)
+    w.mul_(0.5)
+    b.add_(1.0)
+    o3 = call()
+    _close(o3, torch.from_numpy(odcn.dcn_v2_forward_c(x, w.cpu().numpy(), b.cpu().numpy(), off, m)), 1e-4)
+    assert not torch.equal(o3, o1)
+
+
+@pytest.mark.parametrize("C,Co,dg,tile,S", [(64, 64, 2, 0, 1), (128, 128, 4, 64128, 1), (64, 64, 2, 0, 3), (96, 64, 3, 128064, 1)])
+def test_dcn_v2_kernel_deformable_groups_vs_scalar_oracle(C, Co, dg, tile, S):
+    """cp_dcn_desc.dg at the kernel level (NHWC `om` with per-group offsets then per-group mask LOGITS, om_sigmoid=True), incl. the
+    split-K form and the 64x128 / 128x64 tiles, against the scalar oracle."""
+    from centerpose_amd import ops
+    from oracle import dcn as odcn
+    r = np.random.RandomState(C + dg + S)
+    B, H, W, kk = 2, 9, 12, 9
+    x = r.randn(B, C, H, W).astype(np.float32)
+    w = (r.randn(Co, C, 3, 3) / (3 * C ** 0.5)).astype(np.float32)
+    b = r.randn(Co).astype(np.float32)
+    off = (r.randn(B, 2 * dg * kk, H, W) * 3.0).astype(np.float32)
+    lg, m = _dcn_mask_logits(C + dg, (B, dg * kk, H, W))
+    ref = np.maximum(odcn.dcn_v2_forward_c(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, dg), 0.0)
+    omld = ops.round_up(3 * dg * kk, 4)
+    om = torch.zeros(B, H, W, omld)
+    om[..., :2 * dg * kk] = torch.from_numpy(off).permute(0, 2, 3, 1)
+    om[..., 2 * dg * kk:3 * dg * kk] = torch.from_numpy(lg).permute(0, 2, 3, 1)
+    wp = ops.pack_conv_weight(torch.from_numpy(w).cuda())
+    sc, sh = ops.fold_bn(Co, None, torch.from_numpy(b).cuda())
+    out = torch.empty(B, H, W, Co, device="cuda")
+    if S > 1:
+        ldw = wp.shape[0]
+        ws = torch.full((S, B * H * W, ldw), float("nan"), device="cuda")
+        ops.dcn_v2_launch(_nhwc(torch.from_numpy(x)), om.cuda(), wp, torch.ones(ldw, device="cuda"), torch.zeros(ldw, device="cuda"), ws,
+                          cout=ldw, om_sigmoid=True, tile=tile, ksplit=S, dg=dg).run()
+        ops.splitk_reduce_launch(ws, sc, sh, out, cout=Co, act=ops.ACT_RELU).run()
+    else:
+        ops.dcn_v2(_nhwc(torch.from_numpy(x)), om.cuda(), wp, sc, sh, out, cout=Co, om_sigmoid=True, act=ops.ACT_RELU, tile=tile, dg=dg)
+    _close(out.permute(0, 3, 1, 2), torch.from_numpy(ref), 1e-4)
+
+
 @pytest.mark.parametrize("cin,cout,hw,B", [(16, 16, (24, 40), 2), (16, 64, (8, 16), 1), (64, 64, (20, 28), 3), (32, 27, (16, 16), 2),
                                            (48, 128, (9, 35), 2), (128, 192, (16, 16), 2)])
 def test_conv3x3_patch_kernel(cin, cout, hw, B):

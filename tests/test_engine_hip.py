@@ -259,6 +259,34 @@ def test_pybind_ext_plan_and_decode(tmp_path, golden_dir):
     t = {k: torch.from_numpy(v).cuda() for k, v in gen(**kw).items()}
     d = _ext.multi_pose_decode(t["hm"], t["wh"], t["hps"], t["reg"], t["hm_hp"], t["hp_offset"], K)
     assert np.array_equal(d.cpu().numpy(), g["dets"])
+    # optional index outputs: the same tensors the Python face returns, bit-equal to the reference's own indices
+    d2, inds, hm_inds, scores = _ext.multi_pose_decode(t["hm"], t["wh"], t["hps"], t["reg"], t["hm_hp"], t["hp_offset"], K, return_indices=True)
+    p2, pinds, phm, pscores = multi_pose_decode(t["hm"], t["wh"], t["hps"], reg=t["reg"], hm_hp=t["hm_hp"], hp_offset=t["hp_offset"], K=K,
+                                                 return_indices=True)
+    assert torch.equal(d2, d) and torch.equal(inds, pinds) and torch.equal(hm_inds, phm) and torch.equal(scores, pscores)
+    assert np.array_equal(inds.cpu().numpy(), g["inds"]) and np.array_equal(hm_inds.cpu().numpy(), g["hm_inds"])
+
+
+@pytest.mark.parametrize("arch,head_conv", [("dla_34", 256), ("res_50", 64)])
+def test_pybind_ext_plan_create_from_state_dict(arch, head_conv):
+    """SURVEY 8b item 3 as written: plan_create(arch, state_dict tensors, B, H, W) -- `_ext.plan_create_from_state_dict` compiles the
+    reference-format checkpoint (with a 'module.' prefix, as DataParallel checkpoints have: model.py:76-80) straight into a C plan
+    handle, no plan file; heads / dets equal the Python engine's bits."""
+    from centerpose_amd import _ext, engine, synth
+    from centerpose_amd.decode import multi_pose_decode
+    sd = synth.make_state_dict(arch, head_conv=head_conv)
+    x = synth.make_images(2, 128, 160, seed=9).cuda()
+    ref = [t.clone() for t in engine.Engine(arch, sd, 2, 128, 160, head_conv=head_conv, use_graph=False)(x)]
+    ref_dets = multi_pose_decode(ref[0], ref[1], ref[2], reg=ref[3], hm_hp=ref[4], hp_offset=ref[5], K=100)
+    h = _ext.plan_create_from_state_dict(arch, {"module." + k: v for k, v in sd.items()}, 2, 128, 160, head_conv, True)
+    for _ in range(3):
+        outs = _ext.plan_forward(h, x)
+        dets = _ext.plan_process(h, x, 100)
+    torch.cuda.synchronize()
+    assert len(outs) == 6 and all(torch.equal(a, b) for a, b in zip(outs, ref)) and torch.equal(dets, ref_dets)
+    _ext.plan_destroy(h)
+    with pytest.raises(Exception):
+        _ext.plan_create_from_state_dict(arch, {k: v for k, v in sd.items() if "hm" not in k}, 2, 128, 160, head_conv, True)
 
 
 def test_c_plan_rejects_bad_files(tmp_path):
