@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_arch(lib):
-    assert lib.cp_abi_version() == 3
+    assert lib.cp_abi_version() == 4
     assert lib.cp_target_arch() == b"gfx950"
 
 
