@@ -56,6 +56,10 @@ ARCH_PRESETS = {  # the MODEL / TEST values of experiments/dla_34_512x512.yaml, 
     "shufflenetV2": {"MODEL": {"NAME": "shufflenetV2", "HEAD_CONV": 256, "INTERMEDIATE_CHANNEL": 256},
                      "TEST": {"FLIP_TEST": True, "NMS": False, "FIX_RES": False, "TEST_SCALES": [1]}},
 }
+# resdcn (resnet_dcn.py; no experiment yaml ships for it: the res_50 test settings, CenterNet's head_conv 64 for the ResNet-DCN family)
+for _n in (18, 34, 50, 101):
+    ARCH_PRESETS["resdcn_%d" % _n] = {"MODEL": {"NAME": "resdcn_%d" % _n, "HEAD_CONV": 64, "INTERMEDIATE_CHANNEL": 64},
+                                      "TEST": {"FLIP_TEST": True, "NMS": False, "FIX_RES": True, "TEST_SCALES": [1]}}
 
 
 def get_default_cfg():

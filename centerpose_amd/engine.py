@@ -18,13 +18,14 @@ from . import _lib, nets, ops
 from .nets import Act
 
 
-def normalize_state_dict(sd):
-    """load_model's key fix-up (lib/models/model.py:76-80): strip a leading 'module.'."""
+def normalize_state_dict(sd, arch=None):
+    """load_model's key fix-up (lib/models/model.py:76-80): strip a leading 'module.'; with `arch`, also map the checkpoint's keys
+    onto the graph's (`nets.internal_key`: the stand-alone `resdcn` model has no backbone_model. / head_model. prefixes)."""
     out = {}
     for k, v in sd.items():
         if k.startswith("module") and not k.startswith("module_list"):
             k = k[7:]
-        out[k] = v
+        out[nets.internal_key(arch, k) if arch is not None else k] = v
     return out
 
 
@@ -437,8 +438,8 @@ class Engine:
         self.arch = nets.canonical_arch(arch)
         self.B, self.H, self.W = batch, height, width
         self.device = torch.device(device)
-        sd = normalize_state_dict(state_dict)
-        spec, _ = nets.param_spec(self.arch, height, width, head_conv)
+        sd = normalize_state_dict(state_dict, self.arch)
+        spec, _ = nets.param_spec(self.arch, height, width, head_conv, internal=True)
         missing = [k for k in spec if k not in sd and not k.endswith("num_batches_tracked")]
         if missing:
             raise KeyError("checkpoint is missing %d parameters, e.g. %s" % (len(missing), missing[:3]))

@@ -13,13 +13,17 @@ Structure follows the reference modules (they are *not* imported):
            BasicBlock :29-57, DeformConv :336-348, IDAUp :351-377, DLAUp :381-404, DLASeg :437-447
   res_50   lib/models/backbones/msra_resnet.py    Bottleneck :64-102, PoseResNet :113-208
   hrnet    lib/models/backbones/pose_higher_hrnet.py :98-235, :245-503 + experiments/hrnet_w32_512.yaml:63-130
+  resdcn_N lib/models/backbones/resnet_dcn.py     BasicBlock :34-63, Bottleneck :66-103, PoseResNet :130-276 (N = 18 / 34 / 50 / 101)
   head     lib/models/heads/keypoint.py:14-42
 """
 from collections import OrderedDict
 
 HEADS = (("hm", 1), ("wh", 2), ("hps", 34), ("reg", 2), ("hm_hp", 17), ("hp_offset", 2))
 # (INTERMEDIATE_CHANNEL, HEAD_CONV) per experiments/*.yaml
-ARCH_HEAD = {"dla_34": (64, 256), "res_50": (256, 64), "hrnet": (32, 64), "mobilenetv3": (24, 256), "shufflenetV2": (256, 256)}
+ARCH_HEAD = {"dla_34": (64, 256), "res_50": (256, 64), "hrnet": (32, 64), "mobilenetv3": (24, 256), "shufflenetV2": (256, 256),
+             "resdcn_18": (64, 64), "resdcn_34": (64, 64), "resdcn_50": (64, 64), "resdcn_101": (64, 64)}
+RESDCN_SPEC = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]),
+               101: ("bottleneck", [3, 4, 23, 3])}                       # resnet_dcn.py:270-274
 
 
 class Act:
@@ -215,6 +219,44 @@ class Graph:
             inpl = 256
         return x
 
+    # ---- ResNet + three (DCN, dense deconv) stages: `resdcn` (resnet_dcn.py) ------------------------
+    def resdcn(self, x, num_layers, p="backbone_model"):
+        """PoseResNet.forward resnet_dcn.py:246-258: 7x7/s2 stem, 3x3/s2 max-pool, layer1..4 (BasicBlock for 18 / 34, Bottleneck for
+        50 / 101; downsample = 1x1 conv + BN where stride or width changes, :188-195), then deconv_layers = 3 x [DCN 3x3 + BN + ReLU,
+        ConvTranspose2d(k4, s2, p1, no bias) + BN + ReLU] with 256 / 128 / 64 filters (:214-244).  The reference's own factory
+        cannot construct this model (model.py:52 calls backbone(num_layers=, cfg=) but resnet_dcn.get_pose_net takes (num_layers,
+        heads, head_conv), :284, and builds its own heads as attributes hm / wh / ...); the checkpoint format is therefore
+        PoseResNet's own: un-prefixed keys (`reference_key`)."""
+        kind, reps = RESDCN_SPEC[num_layers]
+        exp = 1 if kind == "basic" else 4
+        x = self.conv(x, p + ".conv1", p + ".bn1", 64, 7, 2, 3, relu=True, stem=True)
+        x = self.emit_maxpool(x, 3, 2, 1)
+        inpl = 64
+        for li, (planes, n, stride) in enumerate(zip([64, 128, 256, 512], reps, [1, 2, 2, 2]), start=1):
+            for b in range(n):
+                q = "%s.layer%d.%d" % (p, li, b)
+                s = stride if b == 0 else 1
+                res = x
+                if b == 0 and (s != 1 or inpl != planes * exp):
+                    res = self.conv(x, q + ".downsample.0", q + ".downsample.1", planes * exp, 1, s, 0)
+                if kind == "basic":
+                    h = self.conv(x, q + ".conv1", q + ".bn1", planes, 3, s, 1, relu=True)
+                    x = self.conv(h, q + ".conv2", q + ".bn2", planes, 3, 1, 1, relu=True, res=res)
+                else:
+                    h = self.conv(x, q + ".conv1", q + ".bn1", planes, 1, relu=True)
+                    h = self.conv(h, q + ".conv2", q + ".bn2", planes, 3, s, 1, relu=True)
+                    x = self.conv(h, q + ".conv3", q + ".bn3", planes * exp, 1, relu=True, res=res)
+                inpl = planes * exp
+        for d, planes in enumerate([256, 128, 64]):
+            q = "%s.deconv_layers." % p
+            x = self.dcn_bn_relu(x, q + str(6 * d), q + str(6 * d + 1), planes)
+            self.spec[q + str(6 * d + 3) + ".weight"] = (planes, planes, 4, 4)
+            self.p_bn(q + str(6 * d + 4), planes)
+            x_in = x
+            x = self.emit_deconv4(x, q + str(6 * d + 3), q + str(6 * d + 4), planes)
+            self.flops += 2 * x_in.H * x_in.W * planes * planes * 16
+        return x
+
     # ---- HRNet-W32 ---------------------------------------------------------------------------
     def _hr_basic(self, x, p):
         h = self.conv(x, p + ".conv1", p + ".bn1", x.C, 3, 1, 1, relu=True)
@@ -352,8 +394,11 @@ class Graph:
     def network(self, arch, x, head_conv=None):
         base = canonical_arch(arch)
         inter, hc = ARCH_HEAD[base]
-        feat = {"dla_34": self.dla34, "res_50": self.res50, "hrnet": self.hrnet_w32, "mobilenetv3": self.mobilenetv3,
-                "shufflenetV2": self.shufflenetv2}[base](x)
+        if base.startswith("resdcn_"):
+            feat = self.resdcn(x, int(base.split("_")[1]))
+        else:
+            feat = {"dla_34": self.dla34, "res_50": self.res50, "hrnet": self.hrnet_w32, "mobilenetv3": self.mobilenetv3,
+                    "shufflenetV2": self.shufflenetv2}[base](x)
         assert feat.C == inter
         return self.head(feat, head_conv or hc)
 
@@ -371,11 +416,40 @@ def canonical_arch(arch):
         return "mobilenetv3"
     if a == "shufflenetv2":
         return "shufflenetV2"
-    raise ValueError("unsupported arch %r (the MI355X hot path covers dla_34, res_50, hrnet, mobilenetv3, shufflenetV2)" % arch)
+    if a.startswith("resdcn"):                                   # 'resdcn_18' (model.py:28 'resdcn' + model.py:49-52 'x_N')
+        n = a.replace("resdcn", "").strip("_") or "18"
+        if n.isdigit() and int(n) in RESDCN_SPEC:
+            return "resdcn_%d" % int(n)
+    raise ValueError("unsupported arch %r (the MI355X hot path covers dla_34, res_50, hrnet, mobilenetv3, shufflenetV2, "
+                     "resdcn_18/34/50/101)" % arch)
 
 
-def param_spec(arch, H=512, W=512, head_conv=None):
-    """OrderedDict name -> shape of the reference checkpoint for `arch`, plus algorithmic FLOPs/image."""
+_HEAD_NAMES = tuple(h for h, _ in HEADS)
+
+
+def internal_key(arch, k):
+    """checkpoint key -> the graph's key.  Every model built by BackBoneWithHead already has `backbone_model.` / `head_model.`
+    prefixes (model.py:44-59); `resdcn` is a stand-alone PoseResNet whose keys have none (conv1.weight, hm.0.weight, ...)."""
+    if not canonical_arch(arch).startswith("resdcn_") or k.startswith(("backbone_model.", "head_model.")):
+        return k
+    return ("head_model." if k.split(".", 1)[0] in _HEAD_NAMES else "backbone_model.") + k
+
+
+def reference_key(arch, k):
+    """inverse of `internal_key`: the key as the reference module's state_dict() spells it."""
+    if not canonical_arch(arch).startswith("resdcn_"):
+        return k
+    for pre in ("backbone_model.", "head_model."):
+        if k.startswith(pre):
+            return k[len(pre):]
+    return k
+
+
+def param_spec(arch, H=512, W=512, head_conv=None, internal=False):
+    """OrderedDict name -> shape of the reference checkpoint for `arch`, plus algorithmic FLOPs/image.  Names are the
+    reference's (`reference_key`) unless `internal`."""
     g = Graph()
     g.network(arch, Act(H, W, 3), head_conv)
-    return g.spec, g.flops
+    if internal:
+        return g.spec, g.flops
+    return OrderedDict((reference_key(arch, k), v) for k, v in g.spec.items()), g.flops

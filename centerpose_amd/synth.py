@@ -26,8 +26,10 @@ def _bilinear_up(c, k):
     return np.broadcast_to(w, (c, 1, k, k)).copy()
 
 
-def _feeds_residual_add(name):
+def _feeds_residual_add(name, arch=""):
     """BN whose output is summed with a skip / other branches (gamma scaled down)."""
+    if arch in ("resdcn_18", "resdcn_34") and ".layer" in name and name.endswith(".bn2.weight"):
+        return True                                                   # BasicBlock.bn2 (resnet_dcn.py:52-63)
     if name in ("backbone_model.bn2.weight",):                        # hrnet stem bn2: plain conv-bn-relu
         return False
     if name.endswith((".bn2.weight", ".bn3.weight")) and (".tree" in name or ".layer" in name or ".branches." in name):
@@ -41,7 +43,8 @@ def _feeds_residual_add(name):
 
 
 # empirical damping of the remaining BN gammas so that activations stay O(1) through depth
-GAMMA_DAMP = {"dla_34": 0.8, "res_50": 0.75, "hrnet": 0.62, "mobilenetv3": 0.8, "shufflenetV2": 0.65}
+GAMMA_DAMP = {"dla_34": 0.8, "res_50": 0.75, "hrnet": 0.62, "mobilenetv3": 0.8, "shufflenetV2": 0.65,
+              "resdcn_18": 0.85, "resdcn_34": 0.85, "resdcn_50": 0.75, "resdcn_101": 0.75}
 
 HEAD_TARGET = {  # final 1x1 layer: (output std, bias)
     "hm": (3.0, -1.0), "wh": (4.0, 12.0), "hps": (8.0, 0.0), "reg": (0.2, 0.5), "hm_hp": (3.0, -1.5),
@@ -51,7 +54,8 @@ HEAD_TARGET = {  # final 1x1 layer: (output std, bias)
 
 def make_state_dict(arch, seed=317, head_conv=None, H=512, W=512):
     """dict name -> torch.float32 tensor (CPU) with the reference key names for `arch`."""
-    spec, _ = nets.param_spec(arch, H, W, head_conv)
+    spec, _ = nets.param_spec(arch, H, W, head_conv, internal=True)
+    arch = nets.canonical_arch(arch)
     r = np.random.RandomState(seed)
     sd = {}
     far = 0
@@ -66,7 +70,7 @@ def make_state_dict(arch, seed=317, head_conv=None, H=512, W=512):
             v = r.randn(*shp) * 0.1
         elif len(shp) == 1 and leaf == "weight":                     # BN gamma
             v = r.uniform(0.5, 1.5, shp)
-            v = v * (0.3 if _feeds_residual_add(name) else GAMMA_DAMP[nets.canonical_arch(arch)])
+            v = v * (0.3 if _feeds_residual_add(name, arch) else GAMMA_DAMP[arch])
         elif len(shp) == 1 and "conv_offset_mask" in name:           # offset / mask bias
             v = r.uniform(-1, 1, shp)
             if far % 3 == 0:                                          # some taps sample far outside the map
@@ -96,7 +100,7 @@ def make_state_dict(arch, seed=317, head_conv=None, H=512, W=512):
                 gain *= 1.7                                           # DCN: mask ~ 0.5 on average
             v = r.randn(*shp) * gain
         sd[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
-    return sd
+    return {nets.reference_key(arch, k): v for k, v in sd.items()}      # the reference module's own spelling (resdcn: no prefixes)
 
 
 def make_images(batch, H=512, W=512, seed=317):

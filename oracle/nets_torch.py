@@ -18,6 +18,8 @@ Reference lines:
   mobilenetv3 : lib/models/backbones/mobilenet/mobilenetv3.py (Block :116-144, SeModule :99-113, hswish / hsigmoid :87-96,
              MobileNetV3 :160-222)
   shufflenetV2: lib/models/backbones/shufflenetv2_dcn.py (channel_shuffle :28-42, InvertedResidual :55-104, ShuffleNetV2 :106-222)
+  resdcn_N : lib/models/backbones/resnet_dcn.py (BasicBlock :34-63, Bottleneck :66-103, PoseResNet :130-258); a stand-alone
+             model: its checkpoint keys carry no backbone_model. / head_model. prefixes and its heads are attributes hm / wh / ...
   head     : lib/models/heads/keypoint.py:14-42
 """
 import torch
@@ -143,6 +145,41 @@ def res50_backbone(sd, x, p="backbone_model"):
         x = F.conv_transpose2d(x, sd["%s.deconv_layers.%d.weight" % (p, 3 * i)], None, 2, 1)
         x = F.relu(_bn(sd, "%s.deconv_layers.%d" % (p, 3 * i + 1), x))
     return x
+
+
+# ------------------------------------------------------------------ ResNet + DCN deconv stages (resdcn) ------------
+RESDCN_SPEC = {18: ("basic", [2, 2, 2, 2]), 34: ("basic", [3, 4, 6, 3]), 50: ("bottleneck", [3, 4, 6, 3]), 101: ("bottleneck", [3, 4, 23, 3])}
+
+
+def _res_basic(sd, p, x, stride, has_ds):
+    """resnet_dcn.py:46-63."""
+    out = F.relu(_bn(sd, p + ".bn1", _conv(sd, p + ".conv1", x, stride, 1)))
+    out = _bn(sd, p + ".bn2", _conv(sd, p + ".conv2", out, 1, 1))
+    res = _bn(sd, p + ".downsample.1", _conv(sd, p + ".downsample.0", x, stride)) if has_ds else x
+    return F.relu(out + res)
+
+
+def resdcn_forward(sd, x, num_layers, dcn_impl=None):
+    """PoseResNet.forward resnet_dcn.py:246-258 on the model's own (un-prefixed) state_dict -> [hm, wh, hps, reg, hm_hp, hp_offset]
+    (the reference returns [dict]; the six-tensor list is the order of KeypointHead / multi_pose_decode's arguments)."""
+    kind, reps = RESDCN_SPEC[num_layers]
+    exp = 1 if kind == "basic" else 4
+    x = F.relu(_bn(sd, "bn1", _conv(sd, "conv1", x, 2, 3)))
+    x = F.max_pool2d(x, 3, 2, 1)
+    inpl = 64
+    for li, (planes, n, stride) in enumerate(zip([64, 128, 256, 512], reps, [1, 2, 2, 2]), start=1):
+        for b in range(n):
+            s = stride if b == 0 else 1
+            ds = b == 0 and (s != 1 or inpl != planes * exp)                 # _make_layer :186-201
+            blk = _res_basic if kind == "basic" else _res_bottleneck
+            x = blk(sd, "layer%d.%d" % (li, b), x, s, ds)
+            inpl = planes * exp
+    for d in range(3):                                                       # _make_deconv_layer :214-244
+        q = "deconv_layers."
+        x = F.relu(_bn(sd, q + str(6 * d + 1), dcn_module(sd, q + str(6 * d), x, dcn_impl)))
+        x = F.conv_transpose2d(x, sd[q + str(6 * d + 3) + ".weight"], None, 2, 1)
+        x = F.relu(_bn(sd, q + str(6 * d + 4), x))
+    return [_conv(sd, h + ".2", F.relu(_conv(sd, h + ".0", x, 1, 1))) for h in HEADS]   # :170-184 fc = conv3x3, ReLU, conv1x1
 
 
 # ------------------------------------------------------------------ HRNet-W32 ------------
@@ -345,6 +382,9 @@ DCN_BACKBONES = {"dla_34": dla34_backbone, "mobilenetv3": mobilenetv3_backbone, 
 def forward(arch, sd, images, dcn_impl=None):
     """BackBoneWithHead.forward lib/models/model.py:57-59."""
     with torch.no_grad():
+        if arch.startswith("resdcn_"):
+            strip = lambda k: k.split(".", 1)[1] if k.startswith(("backbone_model.", "head_model.")) else k
+            return resdcn_forward({strip(k): v for k, v in sd.items()}, images, int(arch.split("_")[1]), dcn_impl)
         if arch in DCN_BACKBONES:
             feat = DCN_BACKBONES[arch](sd, images, dcn_impl)
         else:

@@ -13,7 +13,7 @@ import torch
 from oracle import decode_np, nets_torch
 
 pytestmark = pytest.mark.gpu
-ARCHS = ["dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2"]
+ARCHS = ["dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2", "resdcn_18"]
 
 
 def _check_heads(outs, refs):
@@ -27,7 +27,7 @@ def _check_heads(outs, refs):
         assert err <= tol, "%s: max err %.3e > %.3e" % (n, err, tol)
 
 
-@pytest.mark.parametrize("arch", ARCHS)
+@pytest.mark.parametrize("arch", ARCHS + ["resdcn_50"])
 def test_forward_matches_reference_golden(arch, golden_dir):
     from centerpose_amd import engine, synth
     g = np.load(os.path.join(golden_dir, "net_%s_128.npz" % arch))
@@ -39,7 +39,8 @@ def test_forward_matches_reference_golden(arch, golden_dir):
 
 
 @pytest.mark.parametrize("arch,B,hw", [("dla_34", 3, (160, 96)), ("res_50", 2, (96, 160)), ("hrnet", 2, (64, 128)),
-                                       ("mobilenetv3", 2, (96, 160)), ("shufflenetV2", 3, (160, 96))])
+                                       ("mobilenetv3", 2, (96, 160)), ("shufflenetV2", 3, (160, 96)), ("resdcn_18", 3, (96, 160)),
+                                       ("resdcn_50", 2, (160, 96))])
 def test_forward_matches_oracle_ragged_shapes(arch, B, hw):
     """non-square inputs, batch > 1, hipGraph replay (twice: static buffers must be reusable)."""
     from centerpose_amd import engine, synth
@@ -101,6 +102,28 @@ def test_process_end_to_end(arch):
     assert np.allclose(dets[..., :4][stable], ref[..., :4][stable], atol=2e-2)
     # keypoint coordinates: allow rare accept/reject flips at a threshold
     assert close.mean() > 0.995
+
+
+def test_resdcn_through_the_detector():
+    """`resdcn_18` (resnet_dcn.py: the reference's own factory cannot construct it, model.py:52 vs resnet_dcn.py:284) behind the
+    same entry points: create_model -> MultiPoseDetector.process; the dict-of-heads of PoseResNet.forward arrives as the six-tensor
+    list, dets bit-equal to the oracle decode of the engine's maps, heads within the 1e-3 bar of the oracle network."""
+    from centerpose_amd import config, detector, synth
+    cfg = config.get_cfg("resdcn_18", TEST__FLIP_TEST=False)
+    det = detector.MultiPoseDetector(cfg)
+    assert "conv1.weight" in det.model.state_dict() and "hm.2.bias" in det.model.state_dict()
+    x = synth.make_images(2, 256, 192, seed=8)
+    outputs, dets = det.process(x.cuda())
+    torch.cuda.synchronize()
+    o = [t.cpu().numpy() for t in outputs]
+    assert np.array_equal(dets.cpu().numpy(), decode_np.multi_pose_decode(o[0], o[1], o[2], o[3], o[4], o[5], K=100))
+    refs = nets_torch.forward("resdcn_18", det.model.state_dict(), x)
+    for n, got, r in zip(("hm", "wh", "hps", "reg", "hm_hp", "hp_offset"), outputs, refs):
+        got, r = got.cpu().double(), r.double()
+        if n in ("hm", "hm_hp"):
+            r = torch.sigmoid(r)
+        tol = 1e-3 if n in ("hm", "hm_hp", "reg", "hp_offset") else 1e-3 * r.abs().max().item()
+        assert (got - r).abs().max().item() <= tol, n
 
 
 def test_process_flip_test_matches_oracle():

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_param_spec_counts_and_flops():
     from centerpose_amd import nets
     for arch, nkeys, gf in (("dla_34", 410, 80.34), ("res_50", 360, 86.85), ("hrnet", 1776, 85.27), ("mobilenetv3", 471, 15.59),
-                            ("shufflenetV2", 399, 136.27)):
+                            ("shufflenetV2", 399, 136.27), ("resdcn_18", 189, 30.19), ("resdcn_50", 387, 55.95)):
         spec, flops = nets.param_spec(arch)
         assert len(spec) == nkeys                      # 410 / 360 entries (probe of the reference)
         assert abs(flops / 1e9 - gf) < 0.05
@@ -29,7 +29,7 @@ def test_synth_is_deterministic_and_complete():
 
 
 @pytest.mark.reference
-@pytest.mark.parametrize("arch", ["dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2"])
+@pytest.mark.parametrize("arch", ["dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2", "resdcn_18", "resdcn_34", "resdcn_50"])
 def test_spec_and_oracle_match_imported_reference(arch):
     """key names/shapes == the reference module's state_dict; torch oracle == reference forward."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
@@ -54,7 +54,7 @@ def test_spec_and_oracle_match_imported_reference(arch):
 def test_oracle_matches_reference_golden_nets(golden_dir):
     from centerpose_amd import synth
     from oracle import nets_torch
-    for arch in ("dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2"):
+    for arch in ("dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2", "resdcn_18", "resdcn_50"):
         g = np.load(os.path.join(golden_dir, "net_%s_128.npz" % arch))
         out = nets_torch.forward(arch, synth.make_state_dict(arch), synth.make_images(1, 128, 128, seed=7))
         for i, o in enumerate(out):
@@ -323,3 +323,22 @@ def test_order_is_topological_and_list_schedule():
     deps2 = [[], [0], [0, 3], [1], [2], [3, 4]]
     bad = [0, 2, 1, 3, 4, 5]
     assert order_is_topological(deps, bad) and not order_is_topological(deps2, bad)
+
+
+def test_resdcn_checkpoint_keys_are_the_standalone_models():
+    """`resdcn` (resnet_dcn.py) is a stand-alone PoseResNet: its state_dict has no backbone_model. / head_model. prefixes and its
+    heads are attributes (hm.0.weight ...).  The spec / synthetic checkpoint use that spelling; the engine maps it onto the graph's
+    keys (`nets.internal_key`), also under a DataParallel 'module.' prefix."""
+    from centerpose_amd import engine, nets, synth
+    spec, _ = nets.param_spec("resdcn_18")
+    assert "conv1.weight" in spec and "hm.0.weight" in spec and "deconv_layers.0.conv_offset_mask.weight" in spec
+    assert not any(k.startswith(("backbone_model.", "head_model.")) for k in spec)
+    assert nets.canonical_arch("resdcn_18") == "resdcn_18" and nets.canonical_arch("ResDCN_50") == "resdcn_50"
+    with pytest.raises(ValueError):
+        nets.canonical_arch("resdcn_19")
+    sd = synth.make_state_dict("resdcn_18")
+    assert set(sd) == set(spec)
+    inner = engine.normalize_state_dict({"module." + k: v for k, v in sd.items()}, "resdcn_18")
+    ispec, _ = nets.param_spec("resdcn_18", internal=True)
+    assert set(inner) == set(ispec) and "backbone_model.conv1.weight" in inner and "head_model.hm.0.weight" in inner
+    assert nets.internal_key("dla_34", "backbone_model.base.level0.0.weight") == "backbone_model.base.level0.0.weight"
