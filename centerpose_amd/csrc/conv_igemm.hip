@@ -38,6 +38,11 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         pys -= sub >> 1; pxs -= sub & 1;
         ooys = sub >> 1; ooxs = sub & 1;
     }
+    // split-K (a.ksplit = S > 1; single NHWC source, small-M layers: res_50 layer4's 512 -> 512 stride-2 3x3 at 16x16, B = 8, is 256
+    // blocks of 288 k-steps on 256 CUs): block (tile, split) accumulates the k-steps [sp*nk/S, (sp+1)*nk/S) and stores RAW partial sums
+    // to out + sp*M*outLd (scale = 1, shift = 0, no activation); cp_splitk_reduce_f32 adds the splits in a fixed order and finishes
+    const int S = a.ksplit, ksp = S > 1 ? tile % S : 0;
+    if (S > 1) tile /= S;
     const int NT = a.ldw / BN;
     const int nt = tile % NT, mt = tile / NT;
     const int m0 = mt * BM, n0 = nt * BN;
@@ -52,7 +57,8 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
 #pragma unroll
             for (int r = 0; r < IgAcc<MF>::N; ++r) acc[i][j][r] = 0.f;
 
-    const int nk = a.K / IG_BK;
+    const int nk_all = a.K / IG_BK;
+    const int ks0 = ksp * nk_all / S, nk = (ksp + 1) * nk_all / S;      // this block's k-steps [ks0, nk)
     float4 br[T::B_SLOTS];
 
     if constexpr (!STEM) {
@@ -73,6 +79,11 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         bool aok[T::A_SLOTS];
         // k-walk state (wave-uniform): tap (ky,kx), source index, channel offset inside the source
         int ky = 0, kx = 0, si = 0, cl = 0;
+        if (S > 1) {                                   // (single source) start the walk at k-step ks0
+            const int per_tap = a.srcC[0] / IG_BK, tap = ks0 / per_tap;
+            cl = (ks0 - tap * per_tap) * IG_BK;
+            ky = tap / a.kw; kx = tap - ky * a.kw;
+        }
 
         // current source (pointer / pixel stride / channels) lives in registers and is re-read from the
         // kernel arguments only when the k-walk crosses into the next concatenated source: indexing
@@ -83,8 +94,10 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         // (cl == 0) and reused by its C/16 k-steps; the channel offset rides in the scalar base address, so the steady
         // state issues its gathers with no address VALU (for 1x1 layers that is the whole loop).
         unsigned aoff[T::A_SLOTS];
+        bool fresh = true;                             // the first k-step of a split may start inside a tap (cl != 0)
         auto load_a = [&]() __attribute__((always_inline)) {
-            if (cl == 0) {
+            if (cl == 0 || fresh) {
+                fresh = false;
 #pragma unroll
                 for (int s = 0; s < T::A_SLOTS; ++s) {
                     const int iy = ps[s].iy0 + ky, ix = ps[s].ix0 + kx;
@@ -116,12 +129,12 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         };
 
         load_a(); advance();
-        ig_load_b<T>(a, 0, n0, tid, br, wsub);
+        ig_load_b<T>(a, ks0 * IG_BK, n0, tid, br, wsub);
         store_a(As0);
         ig_store_b<T>(Bs0, tid, br);
         __syncthreads();
         int cur = 0;
-        for (int ks = 0; ks < nk; ++ks) {
+        for (int ks = ks0; ks < nk; ++ks) {
             const bool more = ks + 1 < nk;
             ig_compute<T, MF>(As0 + cur * T::A_FLOATS, Bs0 + cur * T::B_FLOATS, wm0, wn0, lane, acc, [&]() __attribute__((always_inline)) {
                 if (more) { load_a(); advance(); ig_load_b<T>(a, (ks + 1) * IG_BK, n0, tid, br, wsub); }
@@ -190,7 +203,11 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
             cur ^= 1;
         }
     }
-    ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc, ooys, ooxs);
+    if (S > 1) {
+        ConvArgs e = a;
+        e.out = a.out + (size_t)ksp * a.M * a.outLd;
+        ig_epilogue<T, BM, BN, MF>(e, smem, m0, n0, wm0, wn0, lane, tid, acc, ooys, ooxs);
+    } else ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc, ooys, ooxs);
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, bool STEM>
@@ -206,7 +223,11 @@ static int launch_conv(const ConvArgs& a, hipStream_t s)
         const hipError_t e = guard.ensure((const void*)kern, smem_max);
         if (e != hipSuccess) { cp_set_error("conv2d: cannot reserve %d B LDS: %s", smem_max, hipGetErrorString(e)); return 2; }
     }
-    const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN) * (a.nsub > 1 ? a.nsub : 1);
+    if (a.ksplit > 1 && (STEM || a.nsub > 1 || a.nsrc != 1 || a.ksplit > a.K / IG_BK)) {
+        cp_set_error("conv2d: ksplit=%d needs one NHWC source, nsub = 1 and at most K/16 = %d splits", a.ksplit, a.K / IG_BK);
+        return 1;
+    }
+    const int grid = cp_cdiv(a.M, BM) * (a.ldw / BN) * (a.nsub > 1 ? a.nsub : 1) * a.ksplit;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(IG_THREADS), smem, s, a);
     cp_note_kernel("igemm_conv_kernel<%d, %d, %d, %d, %d, %s>", BM, BN, WAVES_M, WAVES_N, MF, STEM ? "true" : "false");
     return 0;
@@ -277,7 +298,9 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
 {
     ConvArgs a;
     if (int rc = conv_args_from_desc(d, src, w, scale, shift, res, out, a)) return rc;
-    CP_CHECK_ARG(a.ksplit == 1, "conv2d: ksplit is implemented by cp_conv3x3_winograd_f32 and cp_dcn_v2_f32 only");
+    CP_CHECK_ARG(a.ksplit == 1 || (!res && d->act == CP_ACT_NONE && !d->outNCHW && !d->inNCHW && d->nsrc == 1 && a.nsub == 1 &&
+                                   d->osy == 1 && d->osx == 1 && d->ooy == 0 && d->oox == 0 && d->OH == d->Ho && d->OW == d->Wo),
+                 "conv2d: split-K writes raw NHWC partial sums (one NHWC source, dense output, no residual, no activation; scale = ones, shift = zeros)");
     hipStream_t s = (hipStream_t)stream;
 
     int tile = d->tile;
@@ -286,7 +309,7 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
                      "conv2d: nsub=4 is the fused k4/s2/p1 deconvolution (2x2 taps, output stride 2)");
         CP_CHECK_ARG(tile == 0 || tile > 1000, "conv2d: nsub needs the generic kernel");
     }
-    if (a.nsub == 1 && (tile == 0 || tile == 3 || tile == 332)) {   // 3x3/s1/p1 NHWC: LDS-resident halo patch kernel (conv3x3_patch.hip)
+    if (a.nsub == 1 && a.ksplit == 1 && (tile == 0 || tile == 3 || tile == 332)) {   // 3x3/s1/p1 NHWC: LDS-resident halo patch kernel (conv3x3_patch.hip)
         const int prc = cp_launch_conv3x3_patch(a, d->inNCHW, s, tile == 332 ? 32 : 0);
         if (prc >= 0) {
             if (prc) return prc;

@@ -83,6 +83,7 @@ class PlanBuilder(nets.Graph):
         self.winograd = os.environ.get("CP_WINOGRAD", "1") != "0"
         self.dcn_splitk = os.environ.get("CP_DCN_SPLITK", "1") != "0"      # split-K for the DCNv2 layers that cannot fill the CUs
         self.wino_splitc = os.environ.get("CP_WINO_SPLITC", "1") != "0"    # split-C for Winograd launches on small maps
+        self.conv_splitk = os.environ.get("CP_CONV_SPLITK", "1") != "0"    # split-K for generic conv launches that cannot fill the CUs
         self.fuse_heads = os.environ.get("CP_FUSE_HEADS", "1") != "0"      # 3x3 + 1x1 of a head branch in one launch
         self._pool_cache = {}
         self.outputs = None
@@ -214,6 +215,19 @@ class PlanBuilder(nets.Graph):
         flops = 2 * Ho * Wo * co * ci * k * k
         if u is not None:
             self.add_wino(conv, flops, srcs[0], wp, u, sc, sh, out.t, out.t.shape[3], self.act_code(relu), rt)
+            return out
+        S = ops.conv_ksplit(self.B * Ho * Wo, wp.shape[0], wp.shape[1]) \
+            if (self.conv_splitk and not stem and len(xs) == 1 and res is None and not (k == 3 and stride == 1 and pad == 1)) else 1
+        if S > 1:
+            # small-M launch (res_50 layer4 at B = 8: 256 blocks on 256 CUs): split-K into a workspace of raw partial sums, then the
+            # fixed-order reduction + BN + activation (deterministic; two launches)
+            ldw, M = wp.shape[0], self.B * Ho * Wo
+            ws = self.pool.take(S * M * ldw)
+            wst = ws[: S * M * ldw].view(S, M, ldw)
+            ones, zeros = torch.ones(ldw, device=self.dev), torch.zeros(ldw, device=self.dev)
+            self.add("conv", conv, flops, ops.conv2d_launch(srcs, wp, ones, zeros, wst, kh=k, kw=k, stride=stride, pad=pad, cout=ldw, ksplit=S))
+            self.add("sum", conv + ".splitk", 0, ops.splitk_reduce_launch(wst, sc, sh, out.t, cout=out.t.shape[3], act=self.act_code(relu)))
+            self.pool.give(ws)
             return out
         self.add("conv", conv, flops,
                  ops.conv2d_launch(srcs, wp, sc, sh, out.t, kh=k, kw=k, stride=stride, pad=pad, cout=out.t.shape[3],

@@ -220,7 +220,7 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
     d.outNCHW = 1 if out_nchw else 0
     d.ksplit = ksplit
     if ksplit > 1:
-        assert wino is not None and res is None and act == ACT_NONE and not out_nchw and out.is_contiguous()
+        assert res is None and act == ACT_NONE and not out_nchw and out.is_contiguous() and (wino is not None or (len(srcs) == 1 and not in_nchw and nsub == 1))
         assert tuple(out.shape[:2]) == (ksplit, B * Ho * Wo) and out.shape[2] >= cout and out.shape[2] % 4 == 0
         d.OH, d.OW, d.outLd = Ho, Wo, out.shape[2]
     elif out_nchw:
@@ -351,6 +351,22 @@ def wino_ksplit(B, H, W, cin, cout):
     while blocks * S < 512 and stages // (2 * S) >= 4:
         S *= 2
     return S if blocks < 256 else 1
+
+
+def conv_ksplit(M, ldw, K):
+    """Split-K factor for a generic implicit-GEMM launch (one NHWC source, no residual) with M output pixels, ldw padded output
+    channels and reduction length K: the smallest S in 2..4 that brings the 64 x 64 tiling to >= 512 blocks while every split keeps
+    >= 16 k-steps of 16; 1 when the launch already has >= 400 blocks.  res_50 B = 8 layer4: 512 -> 512 stride-2 3x3 at 16x16 (256
+    blocks x 288 k-steps, 57 TF) and the 2048 -> 512 1x1 convs (256 blocks x 128 k-steps, 53 TF)."""
+    if ldw % 64 != 0:
+        return 1
+    blocks = ((M + 63) // 64) * (ldw // 64)
+    if blocks >= 400:
+        return 1
+    for S in (2, 3, 4):
+        if blocks * S >= 512 and (K // 16) // S >= 16:
+            return S
+    return 1
 
 
 def dcn_ksplit(M, ldw, taps=9):

@@ -55,8 +55,9 @@ typedef struct cp_conv_desc {
     int nsub;                 /* 0 / 1: one convolution.  4: the four sub-pixel 2x2 convolutions of a dense ConvTranspose2d(k4,s2,p1)
                                  (msra_resnet.py:168-193) in ONE launch: w = [4][ldw][K] (sub g = py*2+px), py = px = 1, osy = osx = 2,
                                  ooy = oox = 0; sub g uses pad (1-py, 1-px) and output phase (py, px) */
-    int ksplit;               /* cp_conv3x3_winograd_f32 only.  0 / 1: none.  S > 1: split over the input channels for maps too small to
-                                 fill the chip: `out` is a workspace [S][B*H*W][outLd] of raw partial outputs (scale = ones, shift =
+    int ksplit;               /* 0 / 1: none.  S > 1: split over the reduction axis for launches too small to fill the chip -- over the
+                                 input channels (cp_conv3x3_winograd_f32) or the k-steps (cp_conv2d_f32: one NHWC source, nsub = 1, dense
+                                 NHWC output): `out` is a workspace [S][B*Ho*Wo][outLd] of raw partial outputs (scale = ones, shift =
                                  zeros, act = CP_ACT_NONE, no residual); cp_splitk_reduce_f32 (ldw = outLd) finishes the layer */
 } cp_conv_desc;
 int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale, const float* shift,

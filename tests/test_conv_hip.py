@@ -637,6 +637,40 @@ def test_conv3x3_winograd_fuzz_vs_direct_kernel():
         _close(outs[1], outs[0], 1e-4)
 
 
+@pytest.mark.parametrize("cin,cout,k,stride,pad,hw,S", [(512, 512, 3, 2, 1, (13, 10), 2), (2048, 512, 1, 1, 0, (6, 5), 4), (256, 128, 3, 2, 1, (9, 9), 3),
+                                                        (64, 64, 1, 1, 0, (7, 9), 4), (48, 192, 3, 2, 1, (8, 8), 27)])
+def test_conv2d_split_k(cin, cout, k, stride, pad, hw, S):
+    """cp_conv_desc.ksplit on the generic implicit-GEMM kernel (round 4: res_50 layer4's small-M launches): splits that start in
+    the middle of a tap, ragged M, the extreme S = K / 16 (one k-step per block); raw partial sums + cp_splitk_reduce_f32 (folded
+    BN + ReLU) == the unsplit launch within fp32 re-association and == torch-CPU; twice -> same bits."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(cin + cout + S)
+    B, (H, W) = 2, hw
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bn = _rand_bn(g, cout)
+    ref = F.relu(_ref_bn(F.conv2d(x, w, None, stride, pad), bn))
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    wp = ops.pack_conv_weight(w.cuda())
+    ldw = wp.shape[0]
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    ws = torch.full((S, B * Ho * Wo, ldw), float("nan"), device="cuda")
+    out = torch.full((B, Ho, Wo, cout), float("nan"), device="cuda")
+    la = ops.conv2d_launch([_nhwc(x)], wp, torch.ones(ldw, device="cuda"), torch.zeros(ldw, device="cuda"), ws, kh=k, kw=k, stride=stride,
+                           pad=pad, cout=ldw, ksplit=S)
+    lb = ops.splitk_reduce_launch(ws, sc, sh, out, cout=cout, act=ops.ACT_RELU)
+    la.run(); lb.run()
+    first = out.clone()
+    la.run(); lb.run()
+    assert torch.equal(first, out) and la.kernel.startswith("igemm_conv_kernel")
+    _close(out.permute(0, 3, 1, 2), ref)
+    whole = torch.empty(B, Ho, Wo, cout, device="cuda")
+    ops.conv2d([_nhwc(x)], wp, sc, sh, whole, kh=k, kw=k, stride=stride, pad=pad, cout=cout, act=ops.ACT_RELU)
+    _close(out, whole, 1e-5)
+    assert ops.conv_ksplit(8 * 16 * 16, 512, 9 * 512) == 2 and ops.conv_ksplit(8 * 16 * 16, 512, 2048) == 2      # res_50 B = 8 layer4
+    assert ops.conv_ksplit(16 * 64 * 64, 128, 9 * 64) == 1 and ops.conv_ksplit(8 * 16 * 16, 512, 128) == 1         # enough blocks / K too short
+
+
 @pytest.mark.parametrize("cin,cout,hw,B", [(32, 32, (16, 16), 1), (64, 64, (20, 28), 3), (32, 27, (19, 16), 2), (48, 128, (9, 35), 2),
                                            (128, 192, (16, 16), 2), (256, 96, (8, 8), 2), (128, 128, (64, 64), 2), (16, 40, (33, 17), 1),
                                            (512, 64, (16, 16), 1)])
