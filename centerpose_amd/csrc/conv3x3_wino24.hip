@@ -18,8 +18,8 @@
 //   * U = G2 g G4^T (cp_winograd24_pack_f32, fp64, rounded once) streams global -> registers in fragment order
 //     [xi][ntile][kc][nu 6][lane][4], one 8-channel chunk ahead, issued from inside the MFMA block;
 //   * per chunk and wave: 12 ds_read_b128 + 36 packed VALU + 6 global loads feed 24 v_mfma_f32_32x32x2f32;
-//   * epilogue: the nu -> 4 output columns transform (A4) in registers, the xi-sum (A2) across the four waves through LDS, two
-//     output columns per pass (the F(2x2) kernel's reduction buffer, twice), then scale / shift + residual + activation.
+//   * epilogue: the nu -> 4 output columns transform (A4) in registers, the xi-sum (A2) across the four waves through LDS in one
+//     pass, then scale / shift + residual + activation.
 // fp32 throughout.  F(4,3) has larger transform constants than F(2,3): the measured error against an fp64 convolution is in
 // tools/wino_check.py / DESIGN.md 7.1.
 #include <type_traits>
@@ -35,7 +35,7 @@
 #define W24_F4 (W24_PH * W24_PW * W24_CGS)         // 1296 float4 per stage
 #define W24_SLOTS ((W24_F4 + IG_THREADS - 1) / IG_THREADS)
 #define W24_LDR 36
-#define W24_RED (8 * 32 * W24_LDR)                 // [xi 4][col 2][tile 32][36] floats (36.9 KB)
+#define W24_RED (16 * 32 * W24_LDR)                // [xi 4][col 4][tile 32][36] floats (73.7 KB): the epilogue's reduction buffer
 #define W24_MAIN (2 * W24_STAGE > W24_RED ? 2 * W24_STAGE : W24_RED)
 #define W24_SMEM_FLOATS (W24_MAIN + 16)
 
@@ -49,74 +49,70 @@ struct W24Grid {
 __device__ __forceinline__ int w24_div(int n, int d, unsigned magic) { return d == 1 ? n : (int)__umulhi((unsigned)n, magic); }
 __device__ __forceinline__ w24_v4 w24_lds4(const float* p) { return *reinterpret_cast<const w24_v4*>(p); }
 
-// Output columns 2p, 2p+1 of one accumulator group (32 tiles x 32 channels, the wave's six frequencies): A4 in registers,
-// A2 across the waves through `red`, then scale / shift (+ residual) + activation and float4 NHWC stores.
-template <int P>
-__device__ __forceinline__ void w24_output_cols(const ConvArgs& a, float* red, const f32x16 (&acc)[6], int xi, int h, int m, int tid,
-                                                int b, int y0, int x0, int tile)
+// One accumulator group (32 tiles x 32 channels, the wave's six frequencies) -> output pixels, all four output columns in ONE pass:
+// A4 in registers (the s / d sums once), A2 across the waves through a [xi 4][col 4][tile 32][36] buffer (73.7 KB: still two blocks
+// per CU), four items per thread -- every item of a thread has the same four channels, so scale / shift are loaded once -- then
+// scale / shift (+ residual) + activation and float4 NHWC stores.  (Round 4 first used two passes of two columns through the F(2x2)
+// kernel's 36.9 KB buffer: three barriers and the s / d sums twice; one pass is 2-3 % faster on the 64- / 128-channel layers, same bits.)
+__device__ __forceinline__ void w24_output_all(const ConvArgs& a, float* red, const f32x16 (&acc)[6], int xi, int h, int m, int tid,
+                                               int b, int y0, int x0, int tile)
 {
     const float* const a_res = a.res;
     const bool relu = a.act == CP_ACT_RELU;
     const bool vec_ok = (a.outLd & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
                         (!a_res || ((a.resLd & 3) == 0 && (((size_t)a_res) & 15) == 0));
-    float* wp = red + (xi * 64 + m) * W24_LDR + 4 * h;
+    float* wp = red + (xi * 128 + m) * W24_LDR + 4 * h;           // [xi][col][tile][36]
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         w24_v4 q[6];
 #pragma unroll
         for (int nu = 0; nu < 6; ++nu) q[nu] = (w24_v4){acc[nu][4 * j], acc[nu][4 * j + 1], acc[nu][4 * j + 2], acc[nu][4 * j + 3]};
         const w24_v4 s1 = q[1] + q[2], d1 = q[1] - q[2], s2 = q[3] + q[4], d2 = q[3] - q[4];
-        w24_v4 c0, c1;
-        if constexpr (P == 0) {
-            c0 = (q[0] + s1) + s2;                       // column 0:  m0 + m1 + m2 + m3 + m4
-            c1 = d1 + 2.f * d2;                          // column 1:  m1 - m2 + 2 m3 - 2 m4
-        } else {
-            c0 = s1 + 4.f * s2;                          // column 2:  m1 + m2 + 4 m3 + 4 m4
-            c1 = (d1 + 8.f * d2) + q[5];                 // column 3:  m1 - m2 + 8 m3 - 8 m4 + m5
-        }
-        *reinterpret_cast<w24_v4*>(wp + 8 * j) = c0;
-        *reinterpret_cast<w24_v4*>(wp + 32 * W24_LDR + 8 * j) = c1;
+        *reinterpret_cast<w24_v4*>(wp + 8 * j) = (q[0] + s1) + s2;                               // column 0
+        *reinterpret_cast<w24_v4*>(wp + 32 * W24_LDR + 8 * j) = d1 + 2.f * d2;                   // column 1
+        *reinterpret_cast<w24_v4*>(wp + 64 * W24_LDR + 8 * j) = s1 + 4.f * s2;                   // column 2
+        *reinterpret_cast<w24_v4*>(wp + 96 * W24_LDR + 8 * j) = (d1 + 8.f * d2) + q[5];          // column 3
     }
-    int itn[2], itox[2], itoy[2], itrd[2];
-    bool itok[2], itvec[2];
-    size_t itpix[2];
-    w24_v4 sc[2], sh[2], rr[2][2];
+    const int n4 = tid & 7, n = tile * 32 + n4 * 4;
+    const bool nvec = vec_ok && n + 3 < a.Cout;
+    w24_v4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (nvec) {
+        sc = *reinterpret_cast<const w24_v4*>(a.scale + n);
+        sh = *reinterpret_cast<const w24_v4*>(a.shift + n);
+    }
+    int itox[4], itoy[4], itrd[4];
+    bool itok[4];
+    size_t itpix[4];
+    w24_v4 rr[4][2];
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < 4; ++it) {
         const int item = tid + it * IG_THREADS;
-        const int n4 = item & 7, bb = (item >> 3) & 1, mi = item >> 4;
-        itn[it] = tile * 32 + n4 * 4;
-        itox[it] = x0 + 4 * (mi & 3) + 2 * P + bb;
+        const int col = (item >> 3) & 3, mi = item >> 5;
+        itox[it] = x0 + 4 * (mi & 3) + col;
         itoy[it] = y0 + 2 * (mi >> 2);
-        itrd[it] = (bb * 32 + mi) * W24_LDR + n4 * 4;
-        itok[it] = itox[it] < a.W && itn[it] < a.Cout && itoy[it] < a.H;
-        itvec[it] = itok[it] && vec_ok && itn[it] + 3 < a.Cout;
+        itrd[it] = (col * 32 + mi) * W24_LDR + n4 * 4;
+        itok[it] = itox[it] < a.W && n < a.Cout && itoy[it] < a.H;
         itpix[it] = ((size_t)b * a.H + itoy[it]) * a.W + itox[it];
-        if (itvec[it]) {
-            sc[it] = *reinterpret_cast<const w24_v4*>(a.scale + itn[it]);
-            sh[it] = *reinterpret_cast<const w24_v4*>(a.shift + itn[it]);
-            if (a_res) {
-                rr[it][0] = *reinterpret_cast<const w24_v4*>(a_res + itpix[it] * a.resLd + itn[it]);
-                if (itoy[it] + 1 < a.H) rr[it][1] = *reinterpret_cast<const w24_v4*>(a_res + (itpix[it] + a.W) * a.resLd + itn[it]);
-            }
+        if (itok[it] && nvec && a_res) {
+            rr[it][0] = *reinterpret_cast<const w24_v4*>(a_res + itpix[it] * a.resLd + n);
+            if (itoy[it] + 1 < a.H) rr[it][1] = *reinterpret_cast<const w24_v4*>(a_res + (itpix[it] + a.W) * a.resLd + n);
         }
     }
     __syncthreads();
 #pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    for (int it = 0; it < 4; ++it) {
         if (!itok[it]) continue;
         const float* rp = red + itrd[it];
-        const w24_v4 q0 = w24_lds4(rp), q1 = w24_lds4(rp + 64 * W24_LDR), q2 = w24_lds4(rp + 128 * W24_LDR), q3 = w24_lds4(rp + 192 * W24_LDR);
+        const w24_v4 q0 = w24_lds4(rp), q1 = w24_lds4(rp + 128 * W24_LDR), q2 = w24_lds4(rp + 256 * W24_LDR), q3 = w24_lds4(rp + 384 * W24_LDR);
         w24_v4 yv[2];
         yv[0] = (q0 + q1) + q2;
         yv[1] = (q1 - q2) - q3;
-        const int n = itn[it];
-        if (itvec[it]) {
+        if (nvec) {
 #pragma unroll
             for (int aa = 0; aa < 2; ++aa) {
                 if (itoy[it] + aa >= a.H) continue;
                 const size_t opix = itpix[it] + (size_t)aa * a.W;
-                w24_v4 v = __builtin_elementwise_fma(yv[aa], sc[it], sh[it]);
+                w24_v4 v = __builtin_elementwise_fma(yv[aa], sc, sh);
                 if (a_res) v += rr[it][aa];
                 if (relu) v = (w24_v4){cp_relu(v.x), cp_relu(v.y), cp_relu(v.z), cp_relu(v.w)};
                 else if (a.act != CP_ACT_NONE) { v.x = cp_act(v.x, a.act); v.y = cp_act(v.y, a.act); v.z = cp_act(v.z, a.act); v.w = cp_act(v.w, a.act); }
@@ -308,9 +304,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const Con
     }
 
     if (nb < NTILES) {            // block-uniform (ragged last channel block computes a duplicate that is never stored)
-        w24_output_cols<0>(a, smem, acc, xi, h, m, tid, b, y0, x0, nb);
-        __syncthreads();
-        w24_output_cols<1>(a, smem, acc, xi, h, m, tid, b, y0, x0, nb);
+        w24_output_all(a, smem, acc, xi, h, m, tid, b, y0, x0, nb);
     }
 }
 
@@ -326,7 +320,11 @@ int cp_launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s)
                     (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
     if (!ok) return -1;
     const int smem = W24_SMEM_FLOATS * 4;
-    static_assert(W24_SMEM_FLOATS * 4 <= 64 * 1024, "no dynamic-LDS attribute needed");
+    static CpLdsGuard guard;
+    {
+        const hipError_t e = guard.ensure((const void*)conv3x3_wino24_kernel, smem);
+        if (e != hipSuccess) { cp_set_error("conv3x3_winograd24: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
+    }
     W24Grid gd;
     gd.tilesX = cp_cdiv(a.W, 16); gd.tilesY = cp_cdiv(a.H, 16);
     gd.ntb = (a.Cout + 31) / 32;
