@@ -370,8 +370,10 @@ class PlanBuilder(nets.Graph):
             if per_head:
                 wp3h = ops.pack_conv_weight(self.expand_in(self.w("%s.%s.0.weight" % (p, h)), [feat]))
                 sc3h, sh3h = ops.fold_bn(hc, None, self.w("%s.%s.0.bias" % (p, h)), self.dev)
-                u3h = self.wino(wp3h, feat.t.shape[3], hc, key="%s.%s.0" % (p, h))
-                if u3h is not None and self.fuse_heads and ops.head3x3_1x1_eligible(ft, hc, n):
+                fused_ok = self.fuse_heads and ops.head3x3_1x1_eligible(ft, hc, n)
+                # the fused launch is an F(2x2) kernel; a head that runs as two launches may take the F(2x4) kernel (res_50: 256 -> 64)
+                u3h = self.wino(wp3h, feat.t.shape[3], hc, key="%s.%s.0" % (p, h), hw=None if fused_ok else (H, W))
+                if u3h is not None and fused_ok:
                     # the 1x1 rides in the Winograd kernel (<= 2 outputs: epilogue registers; hps / hm_hp: a second MFMA phase
                     # over the LDS-resident tile): the [B,H,W,hc] intermediate (268 MB at B = 16) is neither written nor read back
                     w2 = self.w("%s.%s.2.weight" % (p, h)).reshape(n, hc).contiguous()
@@ -379,9 +381,14 @@ class PlanBuilder(nets.Graph):
                              ops.head3x3_1x1_launch(ft, u3h, sc3h, sh3h, w2, self.w("%s.%s.2.bias" % (p, h)), o, hc=hc, act2=act))
                     outs.append(o)
                     continue
-                self.add("wino" if u3h is not None else "conv", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9,
-                         ops.conv2d_launch([ft], wp3h, sc3h, sh3h, mid.t, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU,
-                                           wino=u3h))
+                if isinstance(u3h, tuple):
+                    self.add("wino24", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9,
+                             ops.conv2d_launch([ft], wp3h, sc3h, sh3h, mid.t, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU,
+                                               wino=u3h[1], tile=ops.WINO24))
+                else:
+                    self.add("wino" if u3h is not None else "conv", "%s.%s.0" % (p, h), 2 * H * W * hc * feat.C * 9,
+                             ops.conv2d_launch([ft], wp3h, sc3h, sh3h, mid.t, kh=3, kw=3, stride=1, pad=1, cout=hc, act=ops.ACT_RELU,
+                                               wino=u3h))
                 sl = mid.t
             else:
                 sl = mid.t[..., i * hc:(i + 1) * hc]
