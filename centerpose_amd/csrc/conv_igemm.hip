@@ -364,10 +364,12 @@ extern "C" int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const
     CP_CHECK_ARG(d && d->nsrc == 1 && !d->inNCHW && w2 && b2 && out2, "head3x3_1x1: one NHWC source and the 1x1 operands expected");
     if (int rc = conv_args_from_desc(d, srcs, u, scale, shift, nullptr, out2, a)) return rc;
     CP_CHECK_ARG(a.ksplit == 1, "head3x3_1x1: no split-C");
-    const int rc = cp_launch_head3x3_1x1(a, w2, b2, out2, n2, ld2, act2, (hipStream_t)stream);
+    // d->tile == 24: `u` is cp_winograd24_pack_f32's layout and the launch goes to the F(2x4,3x3) head kernel (head_wino24.hip)
+    const int rc = d->tile == 24 ? cp_launch_head3x3_1x1_w24(a, w2, b2, out2, n2, ld2, act2, (hipStream_t)stream)
+                                 : cp_launch_head3x3_1x1(a, w2, b2, out2, n2, ld2, act2, (hipStream_t)stream);
     CP_CHECK_ARG(rc >= 0, "head3x3_1x1: shape not eligible (C = 64, Cmid %% 32 == 0, ReLU, n2 <= 34, 16-byte aligned operands)");
     if (rc) return rc;
-    CP_CHECK_LAUNCH("conv3x3_wino_vs64_kernel");
+    CP_CHECK_LAUNCH("head3x3_1x1 kernel");
     return 0;
 }
 

@@ -374,11 +374,17 @@ class PlanBuilder(nets.Graph):
                 # the fused launch is an F(2x2) kernel; a head that runs as two launches may take the F(2x4) kernel (res_50: 256 -> 64)
                 u3h = self.wino(wp3h, feat.t.shape[3], hc, key="%s.%s.0" % (p, h), hw=None if fused_ok else (H, W))
                 if u3h is not None and fused_ok:
+                    h24 = ops.head_wino24_wanted(ft, n)
+                    if h24:            # F(2x4) head kernel: its own weight transform
+                        ck = ("u24", "%s.%s.0" % (p, h), feat.t.shape[3], hc)
+                        u3h = self.const_cache.get(ck)
+                        if u3h is None:
+                            u3h = self.const_cache[ck] = ops.pack_wino24_weight(wp3h, feat.t.shape[3], hc)
                     # the 1x1 rides in the Winograd kernel (<= 2 outputs: epilogue registers; hps / hm_hp: a second MFMA phase
                     # over the LDS-resident tile): the [B,H,W,hc] intermediate (268 MB at B = 16) is neither written nor read back
                     w2 = self.w("%s.%s.2.weight" % (p, h)).reshape(n, hc).contiguous()
-                    self.add("wino", "%s.%s.0+2" % (p, h), 2 * H * W * (hc * feat.C * 9 + n * hc),
-                             ops.head3x3_1x1_launch(ft, u3h, sc3h, sh3h, w2, self.w("%s.%s.2.bias" % (p, h)), o, hc=hc, act2=act))
+                    self.add("wino24" if h24 else "wino", "%s.%s.0+2" % (p, h), 2 * H * W * (hc * feat.C * 9 + n * hc),
+                             ops.head3x3_1x1_launch(ft, u3h, sc3h, sh3h, w2, self.w("%s.%s.2.bias" % (p, h)), o, hc=hc, act2=act, wino24=h24))
                     outs.append(o)
                     continue
                 if isinstance(u3h, tuple):

@@ -246,9 +246,22 @@ def head3x3_1x1_eligible(x, hc, n2):
     return C == 64 and hc % 32 == 0 and hc >= 128 and 1 <= n2 <= 34 and B * ((H + 7) // 8) * ((W + 15) // 16) >= 512
 
 
-def head3x3_1x1_launch(x, u, scale, shift, w2, b2, out2, *, hc, act2=ACT_NONE):
+def head_wino24_wanted(x, n2):
+    """The fused head launch on the F(2x4,3x3) transform (head_wino24.hip: eight waves per 16x16-pixel block, one block per CU) when
+    the map gives every CU a block.  CP_HEAD24: "0" never, "all" every head, default "1" = the heads it measured faster for
+    (same-process A/B, tools/head_ab.py, B = 16: n2 = 1 0.261 vs 0.288 ms, n2 = 2 0.271 vs 0.293, n2 = 17 0.313 vs 0.335; n2 = 34 0.364
+    vs 0.362: hps keeps the F(2x2) kernel)."""
+    B, H, W, _ = x.shape
+    mode = os.environ.get("CP_HEAD24", "1")
+    if mode == "0" or B * ((H + 15) // 16) * ((W + 15) // 16) < 256:
+        return False
+    return mode == "all" or n2 <= 32
+
+
+def head3x3_1x1_launch(x, u, scale, shift, w2, b2, out2, *, hc, act2=ACT_NONE, wino24=False):
     """One KeypointHead branch (3x3 conv + bias + ReLU -> 1x1 conv + bias [+ sigmoid]) with n2 <= 34 outputs in one launch.
-    x NHWC [B,H,W,64]; u = pack_wino_weight(3x3 weights); scale / shift [>= hc]; w2 [n2, ld2] contiguous; out2 NCHW [B,n2,H,W]."""
+    x NHWC [B,H,W,64]; u = pack_wino_weight(3x3 weights) -- or pack_wino24_weight with wino24=True (the F(2x4) head kernel);
+    scale / shift [>= hc]; w2 [n2, ld2] contiguous; out2 NCHW [B,n2,H,W]."""
     B, H, W, C = x.shape
     n2, ld2 = w2.shape
     assert out2.is_contiguous() and tuple(out2.shape) == (B, n2, H, W) and w2.is_contiguous() and b2.numel() >= n2
@@ -260,7 +273,7 @@ def head3x3_1x1_launch(x, u, scale, shift, w2, b2, out2, *, hc, act2=ACT_NONE):
     d.K, d.ldw, d.Cout = 9 * C, round_up(hc, 64), hc
     d.resLd, d.outLd, d.outNCHW = 0, hc, 0
     d.OH, d.OW, d.osy, d.osx, d.ooy, d.oox = H, W, 1, 1, 0, 0
-    d.act, d.inNCHW, d.tile, d.nsub = ACT_RELU, 0, 0, 1
+    d.act, d.inNCHW, d.tile, d.nsub = ACT_RELU, 0, WINO24 if wino24 else 0, 1
     return Launch("cp_head3x3_1x1_f32", d, [x, u, scale, shift, w2, b2, out2], [n2, ld2, act2])
 
 

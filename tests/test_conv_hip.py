@@ -545,8 +545,10 @@ def test_conv3x3_winograd_kernel(cin, cout, hw, B, nt):
                                                # 33, a full 32, 3 (smallest MM case), ragged tiles, one channel tile only
                                                (2, 32, 48, 256, 17, 2), (1, 37, 45, 256, 34, 0), (3, 8, 16, 128, 33, 0), (1, 19, 9, 64 * 5, 32, 0),
                                                (2, 16, 16, 256, 3, 2), (1, 9, 21, 32, 34, 0), (16, 128, 128, 256, 34, 0)])
-def test_head3x3_1x1_fused(B, H, W, hc, n2, act2):
-    """One KeypointHead branch in ONE launch (keypoint.py:14-37: conv3x3 + bias -> ReLU -> conv1x1 + bias; hm / hm_hp get their
+@pytest.mark.parametrize("w24", [False, True], ids=["f2x2", "f2x4"])
+def test_head3x3_1x1_fused(B, H, W, hc, n2, act2, w24):
+    """(w24: the same launch on the F(2x4,3x3) head kernel -- head_wino24.hip, eight waves per 16x16-pixel block, round 4.)
+    One KeypointHead branch in ONE launch (keypoint.py:14-37: conv3x3 + bias -> ReLU -> conv1x1 + bias; hm / hm_hp get their
     sigmoid, multi_pose.py:35-37): <= 2 outputs ride in the Winograd kernel's epilogue registers, 3..34 outputs (hm_hp, hps) go
     through a second MFMA phase over the LDS-resident ReLU'd tile.  Ragged tiles; the last case is the bench's own shape."""
     from centerpose_amd import ops
@@ -560,13 +562,15 @@ def test_head3x3_1x1_fused(B, H, W, hc, n2, act2):
     if act2 == 2:
         ref = torch.sigmoid(ref)
     wp3 = ops.pack_conv_weight(w3.cuda())
-    u = ops.pack_wino_weight(wp3, 64, hc)
+    u = (ops.pack_wino24_weight if w24 else ops.pack_wino_weight)(wp3, 64, hc)
     sc, sh = ops.fold_bn(hc, None, b3.cuda())
     out = torch.full((B, n2, H, W), float("nan"), device="cuda")
-    ops.head3x3_1x1_launch(_nhwc(x), u, sc, sh, w1.reshape(n2, hc).contiguous().cuda(), b1.cuda(), out, hc=hc, act2=act2).run()
+    la = ops.head3x3_1x1_launch(_nhwc(x), u, sc, sh, w1.reshape(n2, hc).contiguous().cuda(), b1.cuda(), out, hc=hc, act2=act2, wino24=w24)
+    la.run()
+    assert la.kernel.startswith("head_wino24_kernel" if w24 else "conv3x3_wino_vs64_kernel")
     _close(out, ref, 2e-5 if act2 == 2 else 1e-4)
     a = out.clone()
-    ops.head3x3_1x1_launch(_nhwc(x), u, sc, sh, w1.reshape(n2, hc).contiguous().cuda(), b1.cuda(), out, hc=hc, act2=act2).run()
+    la.run()
     assert torch.equal(a, out)             # fixed summation order: deterministic
 
 
