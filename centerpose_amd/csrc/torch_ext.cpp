@@ -48,6 +48,9 @@ at::Tensor nhwc_from_nchw(const at::Tensor& x, int Cpad, int c_off, at::Tensor o
 struct PackedDcn {
     at::Tensor wp, scale, shift;
     int ldw, Cp;
+    // a freed parameter's address can be handed to a NEW tensor with the same version counter: an entry only counts while the
+    // TensorImpls it was built from are alive and are the ones passed in
+    c10::weak_intrusive_ptr<c10::TensorImpl> wimpl{c10::intrusive_ptr<c10::TensorImpl>()}, bimpl{c10::intrusive_ptr<c10::TensorImpl>()};
 };
 struct PackedKey {
     const void *w, *b;
@@ -63,7 +66,11 @@ PackedDcn packed_dcn_weights(const at::Tensor& weight, const at::Tensor& bias, i
     const PackedKey key{weight.data_ptr(), bias.data_ptr(), (int64_t)weight._version(), (int64_t)bias._version(), dg, (int)weight.get_device()};
     std::lock_guard<std::mutex> lock(g_packed_mu);
     auto it = g_packed.find(key);
-    if (it != g_packed.end()) return it->second;
+    if (it != g_packed.end()) {
+        const auto w = it->second.wimpl.lock(), b = it->second.bimpl.lock();
+        if (w.get() == weight.unsafeGetTensorImpl() && b.get() == bias.unsafeGetTensorImpl()) return it->second;
+        g_packed.erase(it);
+    }
     const int Co = weight.size(0), C = weight.size(1), kh = weight.size(2), kw = weight.size(3), kk = kh * kw;
     const int cpg = C / dg, cpgp = (cpg + 15) / 16 * 16, Cp = dg * cpgp, Cop = Co > 17 ? Co : 17;
     const auto opt = weight.options();
@@ -76,6 +83,8 @@ PackedDcn packed_dcn_weights(const at::Tensor& weight, const at::Tensor& bias, i
     r.shift = at::zeros({r.ldw}, opt);
     r.scale.slice(0, 0, Co).fill_(1.0f);
     r.shift.slice(0, 0, Co).copy_(bias);
+    r.wimpl = c10::weak_intrusive_ptr<c10::TensorImpl>(weight.getIntrusivePtr());
+    r.bimpl = c10::weak_intrusive_ptr<c10::TensorImpl>(bias.getIntrusivePtr());
     if (g_packed.size() >= 64) g_packed.clear();
     g_packed[key] = r;
     return r;

@@ -11,11 +11,13 @@ Install under the reference's own wrapper with::
 Inside the fused network plan this entry is NOT used (the engine keeps NHWC end to end and folds
 BN+ReLU); it exists so that the reference's ``DCN`` module itself can run on MI355X.
 """
+import weakref
+
 import torch
 
 from . import _lib, ops
 
-_PACKED = {}          # (weight ptr, weight version, bias ptr, bias version, shape, dg) -> (wp, scale, shift); see _packed_weights
+_PACKED = {}          # (weight ptr, weight version, bias ptr, bias version, shape, dg) -> (weakrefs, wp, scale, shift); see _packed_weights
 _PACKED_MAX = 64
 
 
@@ -37,8 +39,10 @@ def _packed_weights(weight, bias, dg):
     forward (DCNv2/dcn_v2.py:117-127), and re-packing them costs more than the convolution (VERDICT r3 #6)."""
     key = (weight.data_ptr(), weight._version, bias.data_ptr(), bias._version, tuple(weight.shape), dg, weight.device.index)
     hit = _PACKED.get(key)
-    if hit is not None:
-        return hit
+    # a freed parameter's address can be handed to a NEW tensor with the same version counter: an entry only counts while the very
+    # tensor objects it was built from are alive and are the ones passed in
+    if hit is not None and hit[0][0]() is weight and hit[0][1]() is bias:
+        return hit[1:]
     Co, C, kh, kw = weight.shape
     cpg, cpg_p, Cp = _group_pad(C, dg)
     Cop = max(Co, 17)                    # the DCN kernel's smallest N tile is 32: pad tiny Co with zero rows
@@ -53,7 +57,7 @@ def _packed_weights(weight, bias, dg):
     sc, sh = ops.fold_bn(Cop, None, bpad, weight.device)
     if len(_PACKED) >= _PACKED_MAX:
         _PACKED.clear()
-    _PACKED[key] = (wp, sc, sh)
+    _PACKED[key] = ((weakref.ref(weight), weakref.ref(bias)), wp, sc, sh)
     return wp, sc, sh
 
 
