@@ -140,14 +140,14 @@ __device__ __forceinline__ void w24_output_all(const ConvArgs& a, float* red, co
 // asm statements, the literal -5 form of the column transform (two scalar v_fma_f32 per packed one), a run-time stage-buffer
 // offset (13 more address VALU per stage) -- all within the run-to-run noise of +-2 %: the kernel is not bound by its VALU count
 // (PMC: 63 % of a wave's cycles wait for issue behind the other resident waves / barriers, 20 % sit in s_waitcnt).
-__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const ConvArgs a, const W24Grid gd)
+// one block: tile t_ (already XCD-remapped) of the launch / group member described by (a, gd)
+__device__ __forceinline__ void w24_block(const ConvArgs& a, const W24Grid& gd, int t_, float* smem)
 {
     constexpr int CPS = W24_KS / 8;                    // chunks per stage
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, xi = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, m = lane & 31;
     const int NTILES = (a.Cout + 31) >> 5;
-    int t_ = ig_xcd_remap(blockIdx.x, gridDim.x), q_;
+    int q_;
     q_ = w24_div(t_, gd.ntb, gd.mNtb); const int nb = t_ - q_ * gd.ntb; t_ = q_;
     q_ = w24_div(t_, gd.tilesX, gd.mTx); const int tx = t_ - q_ * gd.tilesX; t_ = q_;
     q_ = w24_div(t_, gd.tilesY, gd.mTy); const int ty = t_ - q_ * gd.tilesY;
@@ -308,6 +308,33 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const Con
     }
 }
 
+__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const ConvArgs a, const W24Grid gd)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    w24_block(a, gd, ig_xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+
+// Up to four INDEPENDENT convolutions in one launch (HRNet: the same conv of every parallel branch, pose_higher_hrnet.py:217-235 --
+// 32 ch @128x128, 64 @64x64, 128 @32x32, 256 @16x16 at B = 8 are 512 / 256 / 128 / 64 blocks: launched one by one the small ones leave
+// most of the 256 CUs idle, and ROCm 7.2 captures at most two streams).  Member k owns the tiles [first[k], first[k + 1]); members are
+// ordered longest block first (most input channels), so the short blocks fill the tail.
+struct W24Group {
+    ConvArgs a[4];
+    W24Grid gd[4];
+    int first[5];
+    int n;
+};
+__global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_group_kernel(const W24Group g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // NO XCD remap here: it hands each XCD a contiguous tile range, i.e. all of the longest member's blocks to XCD 0 (measured: 83 us per
+    // group against 75 us for the four launches one by one); consecutive block ids go round-robin over the XCDs, which spreads every member
+    const int t = blockIdx.x;
+    int k = 0;
+    while (k + 1 < g.n && t >= g.first[k + 1]) ++k;            // scalar
+    w24_block(g.a[k], g.gd[k], t - g.first[k], smem);
+}
+
 static unsigned w24_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
 
 // a.w = F(2x4) Winograd-domain weights from cp_winograd24_pack_f32.  Returns -1 when the shape is not eligible.
@@ -334,6 +361,46 @@ int cp_launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s)
     if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd24: grid %lld too large", grid); return 1; }
     hipLaunchKernelGGL(conv3x3_wino24_kernel, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
     cp_note_kernel("conv3x3_wino24_kernel");
+    return 0;
+}
+
+// n <= 4 independent eligible convolutions (each a[i].w = its own cp_winograd24_pack_f32 weights) as ONE launch.
+int cp_launch_conv3x3_wino24_group(const ConvArgs* a, int n, hipStream_t s)
+{
+    if (n < 1 || n > 4) { cp_set_error("conv3x3_winograd24_group: 1..4 members (got %d)", n); return 1; }
+    W24Group g;
+    g.n = n;
+    long long total = 0, dmax = 1;
+    for (int i = 0; i < n; ++i) {
+        const ConvArgs& c = a[i];
+        const bool ok = c.nsrc == 1 && c.kh == 3 && c.kw == 3 && c.sy == 1 && c.sx == 1 && c.py == 1 && c.px == 1 &&
+                        !c.outNCHW && c.osy == 1 && c.osx == 1 && c.ooy == 0 && c.oox == 0 && c.Ho == c.H && c.Wo == c.W &&
+                        c.OH == c.H && c.OW == c.W && c.srcC[0] % 16 == 0 && c.srcLd[0] % 4 == 0 && c.ksplit == 1 &&
+                        (((size_t)c.src[0] | (size_t)c.w) & 15) == 0 && (long long)c.B * c.H * c.W * c.srcLd[0] < (1ll << 31);
+        if (!ok) { cp_set_error("conv3x3_winograd24_group: member %d is not a 3x3 / stride 1 / pad 1 NHWC convolution", i); return 1; }
+        g.a[i] = c;
+        W24Grid& gd = g.gd[i];
+        gd.tilesX = cp_cdiv(c.W, 16); gd.tilesY = cp_cdiv(c.H, 16);
+        gd.ntb = (c.Cout + 31) / 32;
+        gd.mNtb = w24_magic(gd.ntb); gd.mTx = w24_magic(gd.tilesX); gd.mTy = w24_magic(gd.tilesY);
+        g.first[i] = (int)total;
+        const long long blocks = (long long)c.B * gd.tilesX * gd.tilesY * gd.ntb;
+        total += blocks;
+        const long long d = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
+        if (blocks * d >= (1ll << 32)) { cp_set_error("conv3x3_winograd24_group: member %d too large", i); return 1; }
+        if (d > dmax) dmax = d;
+    }
+    for (int i = n; i < 5; ++i) g.first[i] = (int)total;
+    for (int i = n; i < 4; ++i) { g.a[i] = g.a[0]; g.gd[i] = g.gd[0]; }
+    if (total >= (1ll << 31)) { cp_set_error("conv3x3_winograd24_group: grid %lld too large", total); return 1; }
+    const int smem = W24_SMEM_FLOATS * 4;
+    static CpLdsGuard guard;
+    {
+        const hipError_t e = guard.ensure((const void*)conv3x3_wino24_group_kernel, smem);
+        if (e != hipSuccess) { cp_set_error("conv3x3_winograd24_group: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
+    }
+    hipLaunchKernelGGL(conv3x3_wino24_group_kernel, dim3((unsigned)total), dim3(IG_THREADS), smem, s, g);
+    cp_note_kernel("conv3x3_wino24_group_kernel");
     return 0;
 }
 

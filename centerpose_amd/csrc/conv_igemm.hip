@@ -373,6 +373,26 @@ extern "C" int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const
     return 0;
 }
 
+// Up to four INDEPENDENT 3x3 / stride-1 convolutions on the F(2x4,3x3) kernel in ONE launch (HRNet's parallel branches): d[i], src[i],
+// u[i] (cp_winograd24_pack_f32), scale[i], shift[i], res[i] (may be NULL), out[i] describe member i exactly as for
+// cp_conv3x3_winograd_f32 with tile = 24; the members must not alias each other's outputs.
+extern "C" int cp_conv3x3_winograd24_group_f32(const cp_conv_desc* d, int n, const float* const* src, const float* const* u,
+                                               const float* const* scale, const float* const* shift, const float* const* res,
+                                               float* const* out, void* stream)
+{
+    CP_CHECK_ARG(d && src && u && scale && shift && res && out && n >= 1 && n <= 4, "conv3x3_winograd24_group: 1..4 members, no null arrays");
+    ConvArgs a[4];
+    for (int i = 0; i < n; ++i) {
+        const float* srcs[1] = {src[i]};
+        CP_CHECK_ARG(d[i].nsrc == 1 && !d[i].inNCHW, "conv3x3_winograd24_group: member %d: one NHWC source expected", i);
+        if (int rc = conv_args_from_desc(&d[i], srcs, u[i], scale[i], shift[i], res[i], out[i], a[i])) return rc;
+        CP_CHECK_ARG(a[i].ksplit == 1, "conv3x3_winograd24_group: no split launches inside a group");
+    }
+    if (int rc = cp_launch_conv3x3_wino24_group(a, n, (hipStream_t)stream)) return rc;
+    CP_CHECK_LAUNCH("conv3x3_wino24_group_kernel");
+    return 0;
+}
+
 extern "C" int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale,
                                        const float* shift, const float* res, float* out, void* stream)
 {

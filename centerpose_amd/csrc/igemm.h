@@ -67,6 +67,7 @@ struct ConvArgs {
 int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s, int variant = 0);
 // conv3x3_wino.hip (a.w = Winograd-domain weights): same convention
 int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant = 0);
+int cp_launch_conv3x3_wino24_group(const ConvArgs* a, int n, hipStream_t s);      // up to four independent convolutions in one launch
 // head_wino24.hip: the same head branch on the F(2x4,3x3) transform (a.w from cp_winograd24_pack_f32), eight waves per block; -1 = not eligible
 int cp_launch_head3x3_1x1_w24(const ConvArgs& a, const float* w2, const float* b2, float* out2, int n2, int ld2, int act2, hipStream_t s);
 // conv3x3_wino24.hip (a.w = F(2x4,3x3) Winograd-domain weights from cp_winograd24_pack_f32): same convention

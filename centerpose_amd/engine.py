@@ -234,6 +234,37 @@ class PlanBuilder(nets.Graph):
                                    act=self.act_code(relu), res=rt, in_nchw=stem))
         return out
 
+    def emit_conv_group(self, members):
+        """Independent 3x3 / stride-1 convs (HRNet: the same conv of every parallel branch) as ONE F(2x4) launch when every member is
+        eligible (CP_GROUP=0: one launch each).  All outputs live in ONE pool slot: the launch record has a single output storage,
+        which is what `Engine.dependencies` tracks."""
+        ok = self.winograd and os.environ.get("CP_GROUP", "1") != "0" and os.environ.get("CP_WINO24", "1") != "0" and 2 <= len(members) <= 4 and \
+            all(ops.wino_eligible(x.t.shape[3], 3, 1, 1, 1) and not x.split for x, *_ in members)
+        if not ok:
+            return super().emit_conv_group(members)
+        sizes = [self.B * x.H * x.W * ops.round_up(co, 16) for x, _, _, co, _, _ in members]
+        slot = self.pool.take(sum(sizes))
+        holder = Act(1, 1, 1, slot)
+        weakref.finalize(holder, self.pool.give, slot)          # the slot returns to the pool when the last member activation is dropped
+        outs, recs, off, flops = [], [], 0, 0
+        for (x, conv, bn, co, relu, res), n in zip(members, sizes):
+            cp = ops.round_up(co, 16)
+            out = Act(x.H, x.W, co, slot[off:off + n].view(self.B, x.H, x.W, cp), parent=holder)
+            off += n
+            wp = ops.pack_conv_weight(self.expand_in(self.w(conv + ".weight"), [x]))
+            sc, sh = ops.fold_bn(co, self.bn(bn), None, self.dev)
+            cin = x.t.shape[3]
+            ck = ("u24", conv, cin, co)
+            u24 = self.const_cache.get(ck)
+            if u24 is None:
+                u24 = self.const_cache[ck] = ops.pack_wino24_weight(wp, cin, co)
+            recs.append(dict(x=x.t, wp=wp, u24=u24, scale=sc, shift=sh, out=out.t, cout=cp, act=self.act_code(relu),
+                             res=res.t if res is not None else None))
+            flops += 2 * x.H * x.W * co * x.C * 9
+            outs.append(out)
+        self.add("wino24", "group:" + members[0][1], flops, ops.conv3x3_group_launch(recs, slot[:off]))
+        return outs
+
     def emit_maxpool(self, x, k, s, p):
         # a DLA tree pools the same input at every recursion level (pose_dla_dcn.py:197-198,207): emit it once.  Weak
         # references only -- the cache must neither keep a dead activation's storage out of the pool nor match a

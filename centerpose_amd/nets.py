@@ -63,6 +63,11 @@ class Graph:
     def emit_maxpool(self, x, k, s, p):
         return Act((x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1, x.C)
 
+    def emit_conv_group(self, members):
+        """members: [(x, conv, bn, co, relu, res)] -- INDEPENDENT 3x3 / stride-1 / pad-1 conv + BN (+ residual) (+ ReLU) launches that
+        may run as one launch (HRNet's parallel branches).  Default: one after the other."""
+        return [self.emit_conv([x], conv, bn, False, co, 3, 1, 1, relu, res, False) for x, conv, bn, co, relu, res in members]
+
     def emit_dcn(self, x, conv, bn, co):
         return Act(x.H, x.W, co)
 
@@ -265,9 +270,20 @@ class Graph:
     def _hr_module(self, xs, p, chans, multi_scale_output):
         nb = len(chans)
         xs = list(xs)
+        # The parallel branches (pose_higher_hrnet.py:217-222: four BasicBlocks each) are walked level by level: the same conv of every
+        # branch is ONE group of independent launches (`emit_conv_group`).  Parameters are registered branch by branch first, so the
+        # key order of `param_spec` (and with it the seeded synthetic checkpoint) is the reference module's.
         for i in range(nb):
             for b in range(4):
-                xs[i] = self._hr_basic(xs[i], "%s.branches.%d.%d" % (p, i, b))
+                q = "%s.branches.%d.%d" % (p, i, b)
+                for cv, bn in ((".conv1", ".bn1"), (".conv2", ".bn2")):
+                    self.p_conv(q + cv, chans[i], chans[i], 3)
+                    self.p_bn(q + bn, chans[i])
+                    self.flops += 2 * xs[i].H * xs[i].W * chans[i] * chans[i] * 9
+        for b in range(4):
+            q = ["%s.branches.%d.%d" % (p, i, b) for i in range(nb)]
+            hs = self.emit_conv_group([(xs[i], q[i] + ".conv1", q[i] + ".bn1", chans[i], True, None) for i in range(nb)])
+            xs = self.emit_conv_group([(hs[i], q[i] + ".conv2", q[i] + ".bn2", chans[i], True, xs[i]) for i in range(nb)])
         outs = []
         for i in range(nb if multi_scale_output else 1):
             terms, shifts = [], []

@@ -79,6 +79,9 @@ def marshal(fn, desc, ptrs, ints):
         return [d, srcs] + ptrs[4:]
     if fn in ("cp_conv3x3_winograd_f32", "cp_dcn_v2_f32"):      # desc + pointers in order
         return [d] + ptrs
+    if fn == "cp_conv3x3_winograd24_group_f32":   # desc: ConvDesc x 4; ptrs: src x4, u x4, scale x4, shift x4, res x4, out x4, whole; ints: n
+        arr = lambda k: (ctypes.c_void_p * 4)(*[p.value for p in ptrs[4 * k:4 * k + 4]])
+        return [d, ints[0]] + [arr(k) for k in range(6)]
     if fn == "cp_head3x3_1x1_f32":                # ptrs: src, u, scale, shift, w2, b2, out2; ints: n2, ld2, act2
         return [d] + ptrs + ints
     if fn == "cp_stem7x7_f32":                    # ptrs: x, w, scale, shift, out; ints: B, H, W, Cout, stride, outLd, relu
@@ -112,7 +115,7 @@ def marshal(fn, desc, ptrs, ints):
 FN_IDS = {"cp_conv2d_f32": 1, "cp_conv3x3_winograd_f32": 2, "cp_dcn_v2_f32": 3, "cp_stem7x7_f32": 4,
           "cp_maxpool2d_nhwc_f32": 5, "cp_dw_deconv_add_nhwc_f32": 6, "cp_sum_up_nhwc_f32": 7, "cp_dwconv2d_nhwc_f32": 8,
           "cp_global_avgpool_nhwc_f32": 9, "cp_scale_add_nhwc_f32": 10, "cp_shuffle_concat_nhwc_f32": 11, "cp_head3x3_1x1_f32": 12,
-          "cp_decode_topk_f32": 13, "cp_decode_assign_f32": 14, "cp_splitk_reduce_f32": 15}
+          "cp_decode_topk_f32": 13, "cp_decode_assign_f32": 14, "cp_splitk_reduce_f32": 15, "cp_conv3x3_winograd24_group_f32": 16}
 
 
 def pad_rows(t, ldw):
@@ -236,6 +239,28 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
         assert len(srcs) == 1 and not in_nchw
         return Launch("cp_conv3x3_winograd_f32", d, [srcs[0], wino, scale, shift, res, out])
     return Launch("cp_conv2d_f32", d, list(srcs) + [None] * (4 - len(srcs)) + [wp, scale, shift, res, out])
+
+
+ConvDesc4 = ConvDesc * 4
+
+
+def conv3x3_group_launch(members, whole):
+    """Up to four independent 3x3 / stride-1 / pad-1 convolutions on the F(2x4,3x3) kernel in ONE launch (HRNet's parallel branches).
+    members: list of dicts {x, wp, u24, scale, shift, out, cout, act, res}; `whole`: the one storage every `out` is a view of (what
+    the dependency tracking sees as this launch's output).  Members are ordered longest block first."""
+    assert 1 <= len(members) <= 4
+    members = sorted(members, key=lambda mm: -mm["x"].shape[3])
+    d = ConvDesc4()
+    cols = [[None] * 4 for _ in range(6)]
+    for i, mm in enumerate(members):
+        one = conv2d_launch([mm["x"]], mm["wp"], mm["scale"], mm["shift"], mm["out"], kh=3, kw=3, stride=1, pad=1, cout=mm["cout"],
+                            act=mm["act"], res=mm["res"], wino=mm["u24"], tile=WINO24)
+        ctypes.memmove(ctypes.addressof(d[i]), ctypes.addressof(one.desc), ctypes.sizeof(ConvDesc))
+        for k, t in enumerate((mm["x"], mm["u24"], mm["scale"], mm["shift"], mm["res"], mm["out"])):
+            cols[k][i] = t
+            assert t is None or k in (0, 4, 5) or t.is_contiguous()
+        assert mm["out"].untyped_storage().data_ptr() == whole.untyped_storage().data_ptr()
+    return Launch("cp_conv3x3_winograd24_group_f32", d, [t for col in cols for t in col] + [whole], [len(members)])
 
 
 def head3x3_1x1_eligible(x, hc, n2):

@@ -81,6 +81,13 @@ int cp_winograd24_pack_f32(const float* w, float* u, int C, int Cout, void* stre
 int cp_conv3x3_winograd_f32(const cp_conv_desc* d, const float* src, const float* u, const float* scale, const float* shift,
                             const float* res, float* out, void* stream);
 
+/* Up to four INDEPENDENT 3x3 / stride-1 / pad-1 convolutions on the F(2x4,3x3) kernel in ONE launch -- the same convolution of every parallel
+ * HRNet branch (pose_higher_hrnet.py:217-235): launched one by one, the low-resolution branches leave most CUs idle.  Member i = (d[i], src[i],
+ * u[i] from cp_winograd24_pack_f32, scale[i], shift[i], res[i] or NULL, out[i]) as for cp_conv3x3_winograd_f32; outputs must not alias. */
+int cp_conv3x3_winograd24_group_f32(const cp_conv_desc* d, int n, const float* const* src, const float* const* u,
+                                    const float* const* scale, const float* const* shift, const float* const* res,
+                                    float* const* out, void* stream);
+
 /* One KeypointHead branch (lib/models/heads/keypoint.py:14-37: conv3x3(C -> head_conv, bias) -> ReLU -> conv1x1(head_conv -> n, bias))
  * with n <= 34 outputs -- all six branches of the reference head -- as ONE launch: the 1x1 is applied to every channel tile of the
  * Winograd kernel while it is on the CU (n <= 2: in the epilogue registers; more: a second MFMA phase over the LDS-resident tile),
