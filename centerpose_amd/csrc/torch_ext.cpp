@@ -58,7 +58,9 @@ struct PackedKey {
     int dg, dev;
     bool operator<(const PackedKey& o) const { return std::tie(w, b, wv, bv, dg, dev) < std::tie(o.w, o.b, o.wv, o.bv, o.dg, o.dev); }
 };
-std::map<PackedKey, PackedDcn> g_packed;
+// heap-allocated and never destroyed: the entries own device tensors, and a static destructor would release them after the HIP runtime
+// has shut down at interpreter exit
+std::map<PackedKey, PackedDcn>& g_packed = *new std::map<PackedKey, PackedDcn>();
 std::mutex g_packed_mu;
 
 PackedDcn packed_dcn_weights(const at::Tensor& weight, const at::Tensor& bias, int dg)

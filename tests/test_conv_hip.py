@@ -710,6 +710,44 @@ def test_conv3x3_winograd24_kernel(cin, cout, hw, B):
     assert torch.equal(first, out)
 
 
+def test_conv3x3_winograd24_group_launch():
+    """cp_conv3x3_winograd24_group_f32: independent convolutions of different shapes (HRNet's branches: 32 ch on the large map ... 256 ch
+    on the small one) in ONE launch, outputs views of one storage; every member == its own single launch bit for bit (same kernel body,
+    same per-output arithmetic) and == torch-CPU; 2, 3 and 4 members, with / without residual, ragged maps."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(44)
+    shapes = [(32, (40, 24)), (64, (20, 12)), (128, (10, 6)), (256, (5, 3))]
+    B = 2
+    for nm in (2, 3, 4):
+        sizes = [B * h * w * c for c, (h, w) in shapes[:nm]]
+        whole = torch.full((sum(sizes),), float("nan"), device="cuda")
+        members, refs, singles, off = [], [], [], 0
+        for i, (c, (h, w)) in enumerate(shapes[:nm]):
+            x = torch.randn(B, c, h, w, generator=g)
+            wt = torch.randn(c, c, 3, 3, generator=g) / (c * 9) ** 0.5
+            bn = _rand_bn(g, c)
+            res = torch.randn(B, c, h, w, generator=g) if i % 2 == 0 else None
+            y = _ref_bn(F.conv2d(x, wt, None, 1, 1), bn)
+            refs.append(F.relu(y + res) if res is not None else F.relu(y))
+            wp = ops.pack_conv_weight(wt.cuda())
+            u = ops.pack_wino24_weight(wp, c, c)
+            sc, sh = ops.fold_bn(c, tuple(t.cuda() for t in bn))
+            out = whole[off:off + sizes[i]].view(B, h, w, c)
+            off += sizes[i]
+            resn = res.permute(0, 2, 3, 1).contiguous().cuda() if res is not None else None
+            members.append(dict(x=_nhwc(x), wp=wp, u24=u, scale=sc, shift=sh, out=out, cout=c, act=ops.ACT_RELU, res=resn))
+            single = torch.empty(B, h, w, c, device="cuda")
+            ops.conv2d([members[-1]["x"]], wp, sc, sh, single, kh=3, kw=3, stride=1, pad=1, cout=c, act=ops.ACT_RELU, res=resn, wino=u,
+                       tile=ops.WINO24)
+            singles.append(single)
+        la = ops.conv3x3_group_launch(members, whole)
+        la.run()
+        assert la.kernel == "conv3x3_wino24_group_kernel" and not torch.isnan(whole).any()
+        for mm, single, ref in zip(members, singles, refs):
+            assert torch.equal(mm["out"], single)
+            _close(mm["out"].permute(0, 3, 1, 2), ref)
+
+
 def test_conv3x3_winograd24_fuzz_vs_direct_kernel():
     """Seeded random shapes (odd H/W, ragged channel tiles, strided input / output / residual views, every activation): the
     F(2x4) kernel against the direct halo-patch kernel on the same buffers."""
