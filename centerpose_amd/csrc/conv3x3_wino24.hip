@@ -54,25 +54,12 @@ __device__ __forceinline__ w24_v4 w24_lds4(const float* p) { return *reinterpret
 // per CU), four items per thread -- every item of a thread has the same four channels, so scale / shift are loaded once -- then
 // scale / shift (+ residual) + activation and float4 NHWC stores.  (Round 4 first used two passes of two columns through the F(2x2)
 // kernel's 36.9 KB buffer: three barriers and the s / d sums twice; one pass is 2-3 % faster on the 64- / 128-channel layers, same bits.)
-__device__ __forceinline__ void w24_output_all(const ConvArgs& a, float* red, const f32x16 (&acc)[6], int xi, int h, int m, int tid,
-                                               int b, int y0, int x0, int tile)
+__device__ __forceinline__ void w24_output_generic(const ConvArgs& a, float* red, int tid, int b, int y0, int x0, int tile)
 {
     const float* const a_res = a.res;
     const bool relu = a.act == CP_ACT_RELU;
     const bool vec_ok = (a.outLd & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
                         (!a_res || ((a.resLd & 3) == 0 && (((size_t)a_res) & 15) == 0));
-    float* wp = red + (xi * 128 + m) * W24_LDR + 4 * h;           // [xi][col][tile][36]
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        w24_v4 q[6];
-#pragma unroll
-        for (int nu = 0; nu < 6; ++nu) q[nu] = (w24_v4){acc[nu][4 * j], acc[nu][4 * j + 1], acc[nu][4 * j + 2], acc[nu][4 * j + 3]};
-        const w24_v4 s1 = q[1] + q[2], d1 = q[1] - q[2], s2 = q[3] + q[4], d2 = q[3] - q[4];
-        *reinterpret_cast<w24_v4*>(wp + 8 * j) = (q[0] + s1) + s2;                               // column 0
-        *reinterpret_cast<w24_v4*>(wp + 32 * W24_LDR + 8 * j) = d1 + 2.f * d2;                   // column 1
-        *reinterpret_cast<w24_v4*>(wp + 64 * W24_LDR + 8 * j) = s1 + 4.f * s2;                   // column 2
-        *reinterpret_cast<w24_v4*>(wp + 96 * W24_LDR + 8 * j) = (d1 + 8.f * d2) + q[5];          // column 3
-    }
     const int n4 = tid & 7, n = tile * 32 + n4 * 4;
     const bool nvec = vec_ok && n + 3 < a.Cout;
     w24_v4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
@@ -136,11 +123,83 @@ __device__ __forceinline__ void w24_output_all(const ConvArgs& a, float* red, co
     }
 }
 
+// The epilogue proper.  The common case -- 16-byte aligned NHWC output / residual, channel count a multiple of four, no activation or
+// ReLU -- is written for instruction count: an ablation (tools/w24_ablation.py, round 4) put the epilogue at 18 % / 11 % / 7 % of the
+// kernel for 64 / 128 / 256 input channels, ~700 instructions per wave with a quarter of them 64-bit or quarter-rate integer address
+// arithmetic (a v_mul_lo_u32 / v_mad_u64_u32 group per item and row) and thousands of lines of rarely taken paths (scalar tail, sigmoid)
+// around them.  The four items of a thread differ only by four output rows: one 64-bit base per thread, scalar strides, immediate LDS
+// offsets.  Everything else takes the generic function above (same arithmetic, same bits) in the kernels' FAST = false instantiation,
+// chosen on the host (w24_fast_epilogue): the generic code stays out of the common kernel instead of behind a call and its stack frame.
+template <bool FAST>
+__device__ __forceinline__ void w24_output_all(const ConvArgs& a, float* red, const f32x16 (&acc)[6], int xi, int h, int m, int tid,
+                                               int b, int y0, int x0, int tile)
+{
+    float* wp = red + (xi * 128 + m) * W24_LDR + 4 * h;           // [xi][col][tile][36]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w24_v4 q[6];
+#pragma unroll
+        for (int nu = 0; nu < 6; ++nu) q[nu] = (w24_v4){acc[nu][4 * j], acc[nu][4 * j + 1], acc[nu][4 * j + 2], acc[nu][4 * j + 3]};
+        const w24_v4 s1 = q[1] + q[2], d1 = q[1] - q[2], s2 = q[3] + q[4], d2 = q[3] - q[4];
+        *reinterpret_cast<w24_v4*>(wp + 8 * j) = (q[0] + s1) + s2;                               // column 0
+        *reinterpret_cast<w24_v4*>(wp + 32 * W24_LDR + 8 * j) = d1 + 2.f * d2;                   // column 1
+        *reinterpret_cast<w24_v4*>(wp + 64 * W24_LDR + 8 * j) = s1 + 4.f * s2;                   // column 2
+        *reinterpret_cast<w24_v4*>(wp + 96 * W24_LDR + 8 * j) = (d1 + 8.f * d2) + q[5];          // column 3
+    }
+    if (!FAST) {
+        w24_output_generic(a, red, tid, b, y0, x0, tile);
+        return;
+    }
+    const float* const a_res = a.res;
+    // item `it` of this thread is tile (tid >> 5) + 8 it -- tile row (tid >> 7) + 2 it, tile column (tid >> 5) & 3 -- output column
+    // (tid >> 3) & 3, channels 4 (tid & 7) .. + 3: only the tile row changes with `it`, four output rows further down per item
+    const int n4 = tid & 7, col = (tid >> 3) & 3, n = tile * 32 + n4 * 4;
+    const int ox = x0 + 4 * ((tid >> 5) & 3) + col, oyb = y0 + 2 * (tid >> 7);
+    const bool okx = ox < a.W && n < a.Cout;
+    const size_t p0 = ((size_t)b * a.H + oyb) * a.W + ox;
+    float* const op = a.out + p0 * a.outLd + n;
+    const float* const rp0 = a_res ? a_res + p0 * a.resLd + n : nullptr;
+    const int ostep = a.W * a.outLd, rstep = a.W * a.resLd;        // one output row, in floats (scalar registers)
+    w24_v4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (okx) {
+        sc = *reinterpret_cast<const w24_v4*>(a.scale + n);
+        sh = *reinterpret_cast<const w24_v4*>(a.shift + n);
+    }
+    w24_v4 rr[4][2];
+    if (a_res) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it)
+#pragma unroll
+            for (int aa = 0; aa < 2; ++aa)
+                if (okx && oyb + 4 * it + aa < a.H) rr[it][aa] = *reinterpret_cast<const w24_v4*>(rp0 + (4 * it + aa) * rstep);
+    }
+    const float* const rdp = red + (col * 32 + (tid >> 5)) * W24_LDR + n4 * 4;
+    const bool relu = a.act == CP_ACT_RELU;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const float* rp = rdp + it * 8 * W24_LDR;
+        const w24_v4 q0 = w24_lds4(rp), q1 = w24_lds4(rp + 128 * W24_LDR), q2 = w24_lds4(rp + 256 * W24_LDR), q3 = w24_lds4(rp + 384 * W24_LDR);
+        w24_v4 yv[2];
+        yv[0] = (q0 + q1) + q2;
+        yv[1] = (q1 - q2) - q3;
+#pragma unroll
+        for (int aa = 0; aa < 2; ++aa) {
+            if (!(okx && oyb + 4 * it + aa < a.H)) continue;
+            w24_v4 v = __builtin_elementwise_fma(yv[aa], sc, sh);
+            if (a_res) v += rr[it][aa];
+            if (relu) v = (w24_v4){cp_relu(v.x), cp_relu(v.y), cp_relu(v.z), cp_relu(v.w)};
+            *reinterpret_cast<w24_v4*>(op + (4 * it + aa) * ostep) = v;
+        }
+    }
+}
+
 // Measured and NOT kept (same box, same process, tools/bench_conv.py): pinning the transform in front of the MFMA block with empty
 // asm statements, the literal -5 form of the column transform (two scalar v_fma_f32 per packed one), a run-time stage-buffer
 // offset (13 more address VALU per stage) -- all within the run-to-run noise of +-2 %: the kernel is not bound by its VALU count
 // (PMC: 63 % of a wave's cycles wait for issue behind the other resident waves / barriers, 20 % sit in s_waitcnt).
 // one block: tile t_ (already XCD-remapped) of the launch / group member described by (a, gd)
+template <bool FAST>
 __device__ __forceinline__ void w24_block(const ConvArgs& a, const W24Grid& gd, int t_, float* smem)
 {
     constexpr int CPS = W24_KS / 8;                    // chunks per stage
@@ -304,14 +363,15 @@ __device__ __forceinline__ void w24_block(const ConvArgs& a, const W24Grid& gd, 
     }
 
     if (nb < NTILES) {            // block-uniform (ragged last channel block computes a duplicate that is never stored)
-        w24_output_all(a, smem, acc, xi, h, m, tid, b, y0, x0, nb);
+        w24_output_all<FAST>(a, smem, acc, xi, h, m, tid, b, y0, x0, nb);
     }
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_kernel(const ConvArgs a, const W24Grid gd)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    w24_block(a, gd, ig_xcd_remap(blockIdx.x, gridDim.x), smem);
+    w24_block<FAST>(a, gd, ig_xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
 // Up to four INDEPENDENT convolutions in one launch (HRNet: the same conv of every parallel branch, pose_higher_hrnet.py:217-235 --
@@ -324,6 +384,7 @@ struct W24Group {
     int first[5];
     int n;
 };
+template <bool FAST>
 __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_group_kernel(const W24Group g)
 {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -332,7 +393,15 @@ __global__ __launch_bounds__(IG_THREADS, 2) void conv3x3_wino24_group_kernel(con
     const int t = blockIdx.x;
     int k = 0;
     while (k + 1 < g.n && t >= g.first[k + 1]) ++k;            // scalar
-    w24_block(g.a[k], g.gd[k], t - g.first[k], smem);
+    w24_block<FAST>(g.a[k], g.gd[k], t - g.first[k], smem);
+}
+
+// the lean epilogue's preconditions (w24_output_all<true>)
+static bool w24_fast_epilogue(const ConvArgs& a)
+{
+    return (a.outLd & 3) == 0 && (a.Cout & 3) == 0 && (((size_t)a.out) & 15) == 0 &&
+           (!a.res || ((a.resLd & 3) == 0 && (((size_t)a.res) & 15) == 0)) && (a.act == CP_ACT_NONE || a.act == CP_ACT_RELU) &&
+           (long long)a.W * a.outLd * 8 < (1ll << 31) && (long long)a.W * a.resLd * 8 < (1ll << 31);
 }
 
 static unsigned w24_magic(int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); }
@@ -347,9 +416,10 @@ int cp_launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s)
                     (long long)a.B * a.H * a.W * a.srcLd[0] < (1ll << 31);
     if (!ok) return -1;
     const int smem = W24_SMEM_FLOATS * 4;
-    static CpLdsGuard guard;
+    const bool fast = w24_fast_epilogue(a);
+    static CpLdsGuard guard[2];
     {
-        const hipError_t e = guard.ensure((const void*)conv3x3_wino24_kernel, smem);
+        const hipError_t e = guard[fast].ensure(fast ? (const void*)conv3x3_wino24_kernel<true> : (const void*)conv3x3_wino24_kernel<false>, smem);
         if (e != hipSuccess) { cp_set_error("conv3x3_winograd24: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
     }
     W24Grid gd;
@@ -359,7 +429,8 @@ int cp_launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s)
     const long long grid = (long long)a.B * gd.tilesX * gd.tilesY * gd.ntb;
     const long long dmax = gd.ntb > gd.tilesX ? (gd.ntb > gd.tilesY ? gd.ntb : gd.tilesY) : (gd.tilesX > gd.tilesY ? gd.tilesX : gd.tilesY);
     if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd24: grid %lld too large", grid); return 1; }
-    hipLaunchKernelGGL(conv3x3_wino24_kernel, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
+    if (fast) hipLaunchKernelGGL(conv3x3_wino24_kernel<true>, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
+    else hipLaunchKernelGGL(conv3x3_wino24_kernel<false>, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
     cp_note_kernel("conv3x3_wino24_kernel");
     return 0;
 }
@@ -370,6 +441,7 @@ int cp_launch_conv3x3_wino24_group(const ConvArgs* a, int n, hipStream_t s)
     if (n < 1 || n > 4) { cp_set_error("conv3x3_winograd24_group: 1..4 members (got %d)", n); return 1; }
     W24Group g;
     g.n = n;
+    bool fast = true;
     long long total = 0, dmax = 1;
     for (int i = 0; i < n; ++i) {
         const ConvArgs& c = a[i];
@@ -379,6 +451,7 @@ int cp_launch_conv3x3_wino24_group(const ConvArgs* a, int n, hipStream_t s)
                         (((size_t)c.src[0] | (size_t)c.w) & 15) == 0 && (long long)c.B * c.H * c.W * c.srcLd[0] < (1ll << 31);
         if (!ok) { cp_set_error("conv3x3_winograd24_group: member %d is not a 3x3 / stride 1 / pad 1 NHWC convolution", i); return 1; }
         g.a[i] = c;
+        fast = fast && w24_fast_epilogue(c);
         W24Grid& gd = g.gd[i];
         gd.tilesX = cp_cdiv(c.W, 16); gd.tilesY = cp_cdiv(c.H, 16);
         gd.ntb = (c.Cout + 31) / 32;
@@ -394,12 +467,13 @@ int cp_launch_conv3x3_wino24_group(const ConvArgs* a, int n, hipStream_t s)
     for (int i = n; i < 4; ++i) { g.a[i] = g.a[0]; g.gd[i] = g.gd[0]; }
     if (total >= (1ll << 31)) { cp_set_error("conv3x3_winograd24_group: grid %lld too large", total); return 1; }
     const int smem = W24_SMEM_FLOATS * 4;
-    static CpLdsGuard guard;
+    static CpLdsGuard guard[2];
     {
-        const hipError_t e = guard.ensure((const void*)conv3x3_wino24_group_kernel, smem);
+        const hipError_t e = guard[fast].ensure(fast ? (const void*)conv3x3_wino24_group_kernel<true> : (const void*)conv3x3_wino24_group_kernel<false>, smem);
         if (e != hipSuccess) { cp_set_error("conv3x3_winograd24_group: cannot reserve %d B LDS: %s", smem, hipGetErrorString(e)); return 2; }
     }
-    hipLaunchKernelGGL(conv3x3_wino24_group_kernel, dim3((unsigned)total), dim3(IG_THREADS), smem, s, g);
+    if (fast) hipLaunchKernelGGL(conv3x3_wino24_group_kernel<true>, dim3((unsigned)total), dim3(IG_THREADS), smem, s, g);
+    else hipLaunchKernelGGL(conv3x3_wino24_group_kernel<false>, dim3((unsigned)total), dim3(IG_THREADS), smem, s, g);
     cp_note_kernel("conv3x3_wino24_group_kernel");
     return 0;
 }
