@@ -65,6 +65,8 @@ struct ConvArgs {
 
 // conv3x3_patch.hip: returns -1 when the shape is not eligible, else 0 / error code
 int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s, int variant = 0);
+// conv3x3_c16.hip (16 input channels, stride 1 or 2, 16 / 32 outputs): same convention
+int cp_launch_conv3x3_c16(const ConvArgs& a, int in_nchw, hipStream_t s);
 // conv3x3_wino.hip (a.w = Winograd-domain weights): same convention
 int cp_launch_conv3x3_wino(const ConvArgs& a, hipStream_t s, int variant = 0);
 int cp_launch_conv3x3_wino24_group(const ConvArgs* a, int n, hipStream_t s);      // up to four independent convolutions in one launch

@@ -111,6 +111,143 @@ __global__ __launch_bounds__(IG_THREADS) void stem7x7_kernel(const float* __rest
     }
 }
 
+// ---- 16 outputs / stride 1 (DLA-34 base_layer @512x512): weights-in-registers, persistent kernel ---------------------------------
+// Same organisation as conv3x3_c16.hip.  The weights are the MFMA A operand, loaded once per block into 37 VGPRs: k is the plain
+// (c, ky, kx) index, 147 -> 148 = 37 MFMAs per 16 pixels (the kernel above pads kx to 8: 44 steps of 4).  A lane's B operand for MFMA m
+// is ONE float of the LDS window, patch[c][y + ky][x + kx] with (c, ky, kx) = k = 4m + (lane >> 4): its address is a per-lane
+// constant (37 more VGPRs, computed once per block) + an immediate for the tile.  D = W x P leaves a lane with four consecutive channels
+// of one pixel: folded BN + ReLU + one float4 NHWC store, no LDS epilogue.  OCC blocks per CU walk the 8x64-pixel block tiles; the next
+// tile's window (3 x 14 x 72 floats, three float4 per thread) is requested before the current tile's MFMAs and parked in registers.
+#define S7C_TH 8
+#define S7C_TW 64
+#define S7C_PH (S7C_TH + 6)
+#define S7C_PW 72                                  // floats per window row: columns ox0 - 4 .. ox0 + 67 (16-byte aligned in the image)
+#define S7C_F4 (3 * S7C_PH * (S7C_PW / 4))         // 756 float4
+#define S7C_SLOTS ((S7C_F4 + IG_THREADS - 1) / IG_THREADS)
+typedef float s7_v4 __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(IG_THREADS, 3) void stem7x7_c16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                      const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                      float* __restrict__ out, int B, int H, int W, int outLd, int relu,
+                                                                      int tilesX, int tilesY, int ntiles)
+{
+    __shared__ __attribute__((aligned(16))) float patch[3 * S7C_PH * S7C_PW];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int slot = ig_xcd_remap(blockIdx.x, gridDim.x);
+
+    // window staging: float4 `idx` = (plane row pr = c * PH + py, quad f): per-thread constants, per tile only scalars change
+    int s_g[S7C_SLOTS], s_l[S7C_SLOTS], s_py[S7C_SLOTS], s_f[S7C_SLOTS];
+#pragma unroll
+    for (int s = 0; s < S7C_SLOTS; ++s) {
+        const int idx = tid + s * IG_THREADS;
+        const int pr = idx / (S7C_PW / 4), f = idx - pr * (S7C_PW / 4);
+        const int c = pr / S7C_PH, py = pr - c * S7C_PH;
+        s_g[s] = (c * H + py) * W + f * 4;
+        s_l[s] = idx < S7C_F4 ? idx * 4 : -1;
+        s_py[s] = py; s_f[s] = f * 4;
+    }
+    float4 v[S7C_SLOTS];
+    auto load_window = [&](int tl) {
+        const int tx = tl % tilesX, r_ = tl / tilesX;
+        const int ty = r_ % tilesY, b = r_ / tilesY;
+        const int iy0 = ty * S7C_TH - 3, ix0 = tx * S7C_TW - 4;
+        const float* xb = x + ((long long)b * 3 * H + iy0) * W + ix0;            // scalar; may point before the image (never loaded from)
+#pragma unroll
+        for (int s = 0; s < S7C_SLOTS; ++s) {
+            const int yy = iy0 + s_py[s], xx = ix0 + s_f[s];
+            v[s] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (s_l[s] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) v[s] = ig_ldg4(xb + s_g[s]);      // W % 4 == 0: a quad is in or out
+        }
+    };
+    auto store_window = [&]() {
+#pragma unroll
+        for (int s = 0; s < S7C_SLOTS; ++s)
+            if (s_l[s] >= 0) *reinterpret_cast<float4*>(patch + s_l[s]) = v[s];
+    };
+
+    int tl = slot;
+    if (tl < ntiles) load_window(tl);
+    // A operand (weights): row n = j, k = 4m + g = (c*7 + ky)*7 + kx, read from the [16][176] pack (k' = (c*7 + ky)*8 + kx); zero for k >= 147.
+    // B operand address of MFMA m: window float (c*PH + ky) * PW + kx + 1 (+ this wave's first row, + pixel j)
+    float wr[37];
+    int ba[37];
+#pragma unroll
+    for (int m = 0; m < 37; ++m) {
+        const int k = 4 * m + g;
+        const int row = k / 7, kx = k - row * 7;           // row = c*7 + ky
+        const int c = row / 7, ky = row - c * 7;
+        const bool kok = k < 147;
+        wr[m] = kok ? w[j * S7_K + row * 8 + kx] : 0.f;
+        ba[m] = kok ? ((c * S7C_PH + ky + wid * (S7C_TH / 4)) * S7C_PW + kx + 1 + j) : j;
+    }
+    const s7_v4 sc = *reinterpret_cast<const s7_v4*>(scale + g * 4), sh = *reinterpret_cast<const s7_v4*>(shift + g * 4);
+    const long long orow = (long long)W * outLd;
+    if (tl < ntiles) store_window();
+    __syncthreads();
+
+    for (; tl < ntiles; tl += gridDim.x) {
+        const int nxt = tl + gridDim.x;
+        if (nxt < ntiles) load_window(nxt);
+        const int tx = tl % tilesX, r_ = tl / tilesX;
+        const int ty = r_ % tilesY, b = r_ / tilesY;
+        const int oyw = ty * S7C_TH + wid * (S7C_TH / 4), oxl = tx * S7C_TW + j;
+        float* const obase = out + ((long long)(b * H + oyw) * W + oxl) * outLd + g * 4;
+#pragma unroll
+        for (int r = 0; r < S7C_TH / 4; ++r) {             // one output row = four 16-pixel tiles multiplied together
+            f32x4 acc[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            float fr[2][4];
+#define S7C_READ(buf, m) _Pragma("unroll") for (int i = 0; i < 4; ++i) fr[buf][i] = patch[ba[m] + r * S7C_PW + i * 16];
+            S7C_READ(0, 0)
+#pragma unroll
+            for (int m = 0; m < 37; ++m) {
+                const int cb = m & 1;
+                if (m + 1 < 37) { S7C_READ(cb ^ 1, m + 1) }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[m], fr[cb][i], acc[i], 0, 0, 0);
+            }
+#undef S7C_READ
+            if (oyw + r < H) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (oxl + i * 16 >= W) continue;
+                    s7_v4 o = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
+                    o = __builtin_elementwise_fma(o, sc, sh);
+                    if (relu) o = (s7_v4){fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)};
+                    *reinterpret_cast<s7_v4*>(obase + r * orow + i * 16 * outLd) = o;
+                }
+            }
+        }
+        if (nxt < ntiles) {            // block-uniform
+            __syncthreads();
+            store_window();
+            __syncthreads();
+        }
+    }
+}
+
+static int launch_stem_c16(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H, int W,
+                           int outLd, int relu, hipStream_t s)
+{
+    const int tilesX = cp_cdiv(W, S7C_TW), tilesY = cp_cdiv(H, S7C_TH);
+    const long long ntiles = (long long)B * tilesX * tilesY;
+    if (ntiles >= (1ll << 31)) { cp_set_error("stem7x7: %lld tiles", ntiles); return 1; }
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        ncu = n;
+    }
+    const long long cap = (long long)ncu * 3;
+    hipLaunchKernelGGL(stem7x7_c16_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(IG_THREADS), 0, s, x, w, scale, shift, out, B, H, W,
+                       outLd, relu, tilesX, tilesY, (int)ntiles);
+    cp_note_kernel("stem7x7_c16_kernel");
+    return 0;
+}
+
 template <int NOUT, int S, int TH, int TW>
 static int launch_stem(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H, int W,
                        int outLd, int relu, hipStream_t s)
@@ -140,7 +277,11 @@ extern "C" int cp_stem7x7_f32(const float* x, const float* w, const float* scale
     CP_CHECK_ARG(outLd >= Cout, "stem7x7: outLd < Cout");
     hipStream_t s = (hipStream_t)stream;
     int rc;
-    if (Cout == 16 && stride == 1) rc = launch_stem<16, 1, 8, 64>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
+    // the persistent kernel needs whole float4 quads inside / outside the image and aligned rows / stores
+    const bool c16 = Cout == 16 && stride == 1 && W % 4 == 0 && outLd % 4 == 0 && (long long)B * 3 * H * W < (1ll << 31) &&
+                     (((size_t)x | (size_t)out | (size_t)scale | (size_t)shift) & 15) == 0;
+    if (c16) rc = launch_stem_c16(x, w, scale, shift, out, B, H, W, outLd, relu, s);
+    else if (Cout == 16 && stride == 1) rc = launch_stem<16, 1, 8, 64>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
     else if (Cout == 64 && stride == 2) rc = launch_stem<64, 2, 8, 32>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
     else if (Cout == 64 && stride == 1) rc = launch_stem<64, 1, 8, 32>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
     else if (Cout == 16 && stride == 2) rc = launch_stem<16, 2, 8, 64>(x, w, scale, shift, out, B, H, W, outLd, relu, s);

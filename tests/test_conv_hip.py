@@ -507,6 +507,45 @@ def test_conv3x3_patch_kernel(cin, cout, hw, B):
     _close(out[..., :cout].permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("cout,s,hw,B,act,with_res,view", [
+    (16, 1, (40, 72), 2, 1, False, False), (32, 2, (37, 70), 2, 1, False, False), (16, 1, (16, 32), 1, 0, True, False),
+    (32, 2, (16, 32), 3, 1, True, True), (32, 1, (19, 45), 2, 1, True, False), (16, 2, (33, 17), 2, 0, False, True),
+    (16, 1, (5, 3), 1, 1, False, False), (32, 2, (2, 3), 1, 1, False, False), (32, 2, (64, 64), 2, 1, False, False)])
+def test_conv3x3_c16_kernel(cout, s, hw, B, act, with_res, view):
+    """Weights-in-registers kernel for 16-channel 3x3 convs (tile=16; DLA level0 / level1, pose_dla_dcn.py:234-246): stride 1 / 2,
+    16 / 32 outputs, image edges and ragged tiles, residual, output written into a channel view of a wider tensor; against the
+    torch-CPU reference and bit-compared with nothing else (its summation order is its own)."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(cout * 7 + s + hw[0])
+    H, W = hw
+    x = torch.randn(B, 16, H, W, generator=g)
+    w = torch.randn(cout, 16, 3, 3, generator=g) / 12.0
+    bn = _rand_bn(g, cout)
+    ref = _ref_bn(F.conv2d(x, w, None, s, 1), bn)
+    Ho, Wo = ref.shape[2:]
+    res = torch.randn(B, cout, Ho, Wo, generator=g) if with_res else None
+    if with_res:
+        ref = ref + res
+    if act:
+        ref = F.relu(ref)
+    wp = ops.pack_conv_weight(w.cuda())
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    full = torch.full((B, Ho, Wo, cout + (16 if view else 0)), float("nan"), device="cuda")
+    out = full[..., 16:] if view else full
+    ops.conv2d([_nhwc(x)], wp, sc, sh, out, kh=3, kw=3, stride=s, pad=1, cout=cout, act=ops.ACT_RELU if act else ops.ACT_NONE,
+               res=_nhwc(res) if with_res else None, tile=16)
+    from centerpose_amd import _lib
+    assert _lib.lib().cp_last_kernel().decode().startswith("conv3x3_c16_kernel")
+    _close(out.permute(0, 3, 1, 2), ref)
+    if view:
+        assert torch.isnan(full[..., :16]).all()
+    # tile = 0 (auto) must pick the same kernel for this shape: same bits
+    out2 = torch.empty(B, Ho, Wo, cout, device="cuda")
+    ops.conv2d([_nhwc(x)], wp, sc, sh, out2, kh=3, kw=3, stride=s, pad=1, cout=cout, act=ops.ACT_RELU if act else ops.ACT_NONE,
+               res=_nhwc(res) if with_res else None)
+    assert torch.equal(out2, out.contiguous())
+
+
 @pytest.mark.parametrize("cin,cout,hw,B,nt", [(16, 32, (24, 40), 2, 0), (64, 64, (20, 28), 3, 11), (64, 64, (20, 28), 3, 12),
                                               (64, 64, (20, 28), 3, 21), (32, 27, (16, 16), 2, 0), (32, 27, (19, 16), 2, 11),
                                               (48, 128, (9, 35), 2, 12), (48, 128, (9, 35), 2, 21), (128, 192, (16, 16), 2, 0),
@@ -780,7 +819,8 @@ def test_conv3x3_winograd24_fuzz_vs_direct_kernel():
         _close(outs[1], outs[0], 1e-4)
 
 
-@pytest.mark.parametrize("cout,s,hw", [(16, 1, (40, 72)), (64, 2, (37, 70)), (16, 1, (512, 512)), (64, 2, (128, 96))])
+@pytest.mark.parametrize("cout,s,hw", [(16, 1, (40, 72)), (64, 2, (37, 70)), (16, 1, (512, 512)), (64, 2, (128, 96)), (16, 1, (37, 52)),
+                                       (16, 1, (13, 50)), (16, 1, (3, 4)), (16, 1, (70, 200))])
 def test_stem7x7_kernel(cout, s, hw):
     """dedicated 7x7 stem (pose_dla_dcn.py:228-232 / msra_resnet.py:118-121) vs torch-CPU."""
     from centerpose_amd import ops
@@ -792,4 +832,7 @@ def test_stem7x7_kernel(cout, s, hw):
     sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
     out = torch.full((2, ref.shape[2], ref.shape[3], cout), float("nan"), device="cuda")
     ops.stem7x7(x.cuda(), ops.pack_stem7_weight(w.cuda()), sc, sh, out, s)
+    from centerpose_amd import _lib
+    # 16 outputs / stride 1 with whole float4 quads per row: the persistent weights-in-registers kernel; everything else the LDS-weights one
+    assert _lib.lib().cp_last_kernel().decode().startswith("stem7x7_c16_kernel" if cout == 16 and s == 1 and hw[1] % 4 == 0 else "stem7x7_kernel<")
     _close(out.permute(0, 3, 1, 2), ref)
