@@ -78,7 +78,9 @@ __global__ __launch_bounds__(TK_THREADS, 8) void nms_topk_kernel(
     unsigned long long* cand = (!CHUNKED || c0 == 0) ? cand0 : cand0 + P;
     if (CHUNKED) __syncthreads();      // previous chunk's merge has finished with keys / cand
     // ---- phase 1: 3x3 NMS (decode.py:10-16; -inf padding == skip out-of-range) -> keys
-    if (!CHUNKED && n <= TK_EPT * TK_THREADS) {
+    const bool fast = !CHUNKED && n <= TK_EPT * TK_THREADS;       // block-uniform: the plane group's keys also fit the threads' registers
+    uint32_t kreg[TK_EPT];
+    if (fast) {
         // LDS-resident plane group: the raw floats are staged in the key buffer once (coalesced), every thread takes the 3x3 maxima of its
         // <= 16 elements from LDS into registers, and the keys replace the floats after a barrier.  (The direct form below does nine
         // dependent global loads and two run-time integer divisions per element: ~a quarter of this kernel's 99 us at 128x128.)
@@ -89,7 +91,6 @@ __global__ __launch_bounds__(TK_THREADS, 8) void nms_topk_kernel(
             for (int e = tid; e < n; e += TK_THREADS) raw[e] = src[e];
         }
         __syncthreads();
-        uint32_t kreg[TK_EPT];
         const bool pow2 = wsh >= 0;
 #pragma unroll
         for (int q = 0; q < TK_EPT; ++q) {
@@ -144,6 +145,25 @@ __global__ __launch_bounds__(TK_THREADS, 8) void nms_topk_kernel(
         const int shift = 24 - 8 * pass;
         if (tid < 256) hist[tid] = 0;
         __syncthreads();
+        // wave-aggregated histogram update: the digit of the first active lane is counted with ONE LDS atomic for all lanes that share it
+        // (NMS zeroes 8/9 of a map and post-sigmoid values share their top byte), the other lanes add theirs one by one
+        auto hist_add = [&](bool act, uint32_t d) {
+            const unsigned long long am = __ballot(act);
+            if (am) {                                                         // wave-uniform
+                const int first = __ffsll((long long)am) - 1;
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readlane((int)d, first);
+                const unsigned long long same = __ballot(act && d == d0);
+                if (lane == first) atomicAdd(&hist[d0], (uint32_t)__popcll(same));
+                if (act && d != d0) atomicAdd(&hist[d], 1u);
+            }
+        };
+        if (fast) {            // keys from registers (round 4: the four passes re-read all keys from LDS: 34 of the kernel's 56 us)
+#pragma unroll
+            for (int q = 0; q < TK_EPT; ++q) {
+                const uint32_t k = kreg[q];
+                hist_add(tid + q * TK_THREADS < n && (k & pmask) == prefix, (k >> shift) & 255u);
+            }
+        } else
         for (int base = 0; base < n; base += TK_THREADS) {
             const int e = base + tid;
             bool act = false;
@@ -153,14 +173,7 @@ __global__ __launch_bounds__(TK_THREADS, 8) void nms_topk_kernel(
                 act = ((k & pmask) == prefix);
                 d = (k >> shift) & 255u;
             }
-            const unsigned long long am = __ballot(act);
-            if (am) {   // wave-aggregated: NMS zeroes 8/9 of a map, so most lanes share a bin
-                const int first = __ffsll((long long)am) - 1;
-                const uint32_t d0 = __shfl(d, first);
-                const unsigned long long same = __ballot(act && d == d0);
-                if (same == am) { if (lane == first) atomicAdd(&hist[d0], (uint32_t)__popcll(am)); }
-                else if (act) atomicAdd(&hist[d], 1u);
-            }
+            hist_add(act, d);
         }
         __syncthreads();
         if (wid == 0) {
