@@ -52,6 +52,20 @@ struct CpLdsGuard {
     }
 };
 
+// Compute units of the current device (persistent kernels size their grid as blocks-per-CU x CUs).  Queried once per device,
+// thread-safe; 256 (MI355X) if the query fails.
+static inline int cp_num_cus()
+{
+    static std::mutex mu;
+    static int cus[16] = {};
+    int d = 0;
+    (void)hipGetDevice(&d);
+    std::lock_guard<std::mutex> lock(mu);
+    int& n = cus[d & 15];
+    if (n <= 0 && (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0)) n = 256;
+    return n;
+}
+
 // activation codes of the C ABI (include/centerpose_hip.h).  h-swish / h-sigmoid as the reference writes them
 // (lib/models/backbones/mobilenet/mobilenetv3.py:87-96): x * relu6(x + 3) / 6 and relu6(x + 3) / 6, true division.
 #define CP_ACT_NONE_ 0

@@ -189,12 +189,7 @@ static int launch_c16(const ConvArgs& a, hipStream_t s)
     const int tilesX = cp_cdiv(a.Wo, TW), tilesY = cp_cdiv(a.Ho, TH);
     const long long ntiles = (long long)a.B * tilesX * tilesY;
     if (ntiles >= (1ll << 31)) { cp_set_error("conv3x3_c16: %lld tiles", ntiles); return 1; }
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        ncu = n;
-    }
+    const int ncu = cp_num_cus();
     const long long cap = (long long)ncu * OCC;             // persistent: OCC resident blocks per CU walk the tiles
     const long long grid = ntiles < cap ? ntiles : cap;
     hipLaunchKernelGGL((conv3x3_c16_kernel<NT, S, TH, TW, OCC, TBW>), dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, tilesX, tilesY, (int)ntiles);

@@ -235,12 +235,7 @@ static int launch_stem_c16(const float* x, const float* w, const float* scale, c
     const int tilesX = cp_cdiv(W, S7C_TW), tilesY = cp_cdiv(H, S7C_TH);
     const long long ntiles = (long long)B * tilesX * tilesY;
     if (ntiles >= (1ll << 31)) { cp_set_error("stem7x7: %lld tiles", ntiles); return 1; }
-    static int ncu = 0;
-    if (!ncu) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        ncu = n;
-    }
+    const int ncu = cp_num_cus();
     const long long cap = (long long)ncu * 3;
     hipLaunchKernelGGL(stem7x7_c16_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(IG_THREADS), 0, s, x, w, scale, shift, out, B, H, W,
                        outLd, relu, tilesX, tilesY, (int)ntiles);

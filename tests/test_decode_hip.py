@@ -85,9 +85,11 @@ def test_hip_decode_error_behaviour():
         cp.multi_pose_decode(t["hm"], t["wh"], t["hps"], t["reg"], t["hm_hp"], None, K=257)
 
 
-@pytest.mark.parametrize("B,H,W,J,K", [(1, 16, 16, 17, 1), (2, 16, 16, 3, 256), (1, 128, 256, 17, 100), (3, 8, 200, 2, 7)])
+@pytest.mark.parametrize("B,H,W,J,K", [(1, 16, 16, 17, 1), (2, 16, 16, 3, 256), (1, 128, 256, 17, 100), (3, 8, 200, 2, 7), (2, 15, 17, 3, 9),
+                                       (1, 127, 129, 2, 100), (2, 64, 256, 2, 130), (1, 128, 129, 1, 64)])
 def test_hip_decode_edge_shapes(B, H, W, J, K):
-    """K = 1, K = 256 (== the whole 16x16 map), the largest LDS-resident map (128x256 = 32768 keys), thin maps."""
+    """K = 1, K = 256 (== the whole 16x16 map), the largest LDS-resident map (128x256 = 32768 keys), thin maps; odd maps whose planes
+    are not 16-byte aligned (scalar staging of the register-resident path), 16 383 / 16 384 / 16 512 keys (either side of its limit)."""
     inp = cases.decode_random(1000 + K, B=B, H=H, W=W, J=J)
     ref, aux = decode_np.multi_pose_decode(inp["hm"], inp["wh"], inp["hps"], inp["reg"], inp["hm_hp"],
                                            inp["hp_offset"], K=K, return_aux=True)
