@@ -12,8 +12,9 @@
 //     (the k order inside a tap is permuted accordingly: MFMA m takes channel 4g + m from k-group g);
 //   * D = W x P leaves a lane with FOUR CONSECUTIVE CHANNELS of one pixel: folded BN + ReLU and one float4 NHWC store per
 //     16-pixel tile, no LDS epilogue, no barrier after the prologue's;
-//   * every LDS address is lane base + immediate; 16x32 (stride 1) / 8x16 (stride 2) output pixels per block, three blocks per CU
-//     hide one another's prologue.
+//   * every LDS address is lane base + immediate; block tiles of 8x32 (stride 1) / 8x16 (stride 2) output pixels;
+//   * PERSISTENT: three or four blocks per CU walk the block tiles and request the next tile's patch before the current tile's MFMAs
+//     (see the loop below: without it the kernel measured exactly what the kernels it replaces did).
 //   stride 2: the patch is stored de-interleaved by column parity, so that the 16 pixels of a tile (input columns 2x + kx) are
 //   consecutive LDS rows again (stride-2 reads of a 20-float pitch would be two-way bank conflicts).
 #include "igemm.h"
