@@ -32,4 +32,4 @@ for name, (B, H, Ci, Co, k, s) in SHAPES.items():
             outs[tl] = out
     fl = 2.0 * B * Ho * Ho * Co * Ci * k * k
     same = all(torch.equal(outs[TILES[0]], outs[tl]) for tl in TILES)
-    print("%-28s" % name, "  ".join("%d: %.4f ms (%.1f TF)" % (tl, min(r), fl / min(r) / 1e9) for tl, r in t.items()), "| identical" if same else "| DIFFERENT %.2e" % max((outs[TILES[0]] - outs[tl]).abs().max().item() for tl in TILES))
+    print("%-28s" % name, "  ".join("%d: %.4f ms (%.1f TF)" % (tl, min(r), fl / min(r) / 1e9) for tl, r in t.items()), "| identical" if same else "| max diff %.2e" % max((outs[TILES[0]] - outs[tl]).abs().max().item() for tl in TILES))
