@@ -116,60 +116,74 @@ __global__ __launch_bounds__(IG_THREADS) void stem7x7_kernel(const float* __rest
 // (c, ky, kx) index, 147 -> 148 = 37 MFMAs per 16 pixels (the kernel above pads kx to 8: 44 steps of 4).  A lane's B operand for MFMA m
 // is ONE float of the LDS window, patch[c][y + ky][x + kx] with (c, ky, kx) = k = 4m + (lane >> 4): its address is a per-lane
 // constant (37 more VGPRs, computed once per block) + an immediate for the tile.  D = W x P leaves a lane with four consecutive channels
-// of one pixel: folded BN + ReLU + one float4 NHWC store, no LDS epilogue.  OCC blocks per CU walk the 8x64-pixel block tiles; the next
-// tile's window (3 x 14 x 72 floats, three float4 per thread) is requested before the current tile's MFMAs and parked in registers.
-#define S7C_TH 8
-#define S7C_TW 64
-#define S7C_PH (S7C_TH + 6)
-#define S7C_PW 72                                  // floats per window row: columns ox0 - 4 .. ox0 + 67 (16-byte aligned in the image)
-#define S7C_F4 (3 * S7C_PH * (S7C_PW / 4))         // 756 float4
-#define S7C_SLOTS ((S7C_F4 + IG_THREADS - 1) / IG_THREADS)
+// of one pixel: folded BN + ReLU + one float4 NHWC store, no LDS epilogue.  Three blocks per CU walk the block tiles; the next
+// tile's window (3 x 14 x 72 floats, three float4 per thread, for the DLA shape) is requested before the current tile's MFMAs and parked in registers.
+// NOUT = 16 / stride 1 (DLA): 8x64-pixel block tiles, a wave owns two output rows.  NOUT = 64 / stride 2 (ResNet conv1, msra_resnet.py:118-121 /
+// resnet_dcn.py): 4x64-pixel tiles, a wave owns 16 of the 64 output CHANNELS for all rows (37 weight registers per wave either way);
+// the window's pixels are then read at stride 2 (even / odd LDS banks: conflict-free).
 typedef float s7_v4 __attribute__((ext_vector_type(4)));
+template <int NOUT, int S>
+struct S7C {
+    static constexpr int TH = NOUT == 16 ? 8 : 4, TW = 64;
+    static constexpr int PH = (TH - 1) * S + 7;                     // window rows per plane
+    static constexpr int PW = ((TW - 1) * S + 1 + 7 + 3) & ~3;      // floats per window row, first column S * ox0 - 4 (16-byte aligned in the image): 72 / 136
+    static constexpr int F4 = 3 * PH * (PW / 4);
+    static constexpr int SLOTS = (F4 + IG_THREADS - 1) / IG_THREADS;
+    static constexpr int RW = NOUT == 16 ? TH / 4 : TH;             // output rows a wave computes
+    static constexpr int OCC = NOUT == 16 ? 3 : 2;                  // resident blocks per CU (168 / 256 VGPRs: no spills with six prefetch slots)
+    static_assert((NOUT == 16 || NOUT == 64) && (S == 1 || S == 2), "stem shapes");
+};
 
-__global__ __launch_bounds__(IG_THREADS, 3) void stem7x7_c16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int NOUT, int S>
+__global__ __launch_bounds__(IG_THREADS, (S7C<NOUT, S>::OCC)) void stem7x7_c16_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                       const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                      float* __restrict__ out, int B, int H, int W, int outLd, int relu,
+                                                                      float* __restrict__ out, int B, int H, int W, int Ho, int Wo, int outLd, int relu,
                                                                       int tilesX, int tilesY, int ntiles)
 {
-    __shared__ __attribute__((aligned(16))) float patch[3 * S7C_PH * S7C_PW];
+    typedef S7C<NOUT, S> G;
+    __shared__ __attribute__((aligned(16))) float patch[3 * G::PH * G::PW];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
+    const int nset = NOUT == 16 ? 0 : wid;                    // this wave's 16 output channels
+    const int wrow = NOUT == 16 ? wid * G::RW : 0;            // this wave's first output row inside the tile
     const int slot = ig_xcd_remap(blockIdx.x, gridDim.x);
 
     // window staging: float4 `idx` = (plane row pr = c * PH + py, quad f): per-thread constants, per tile only scalars change
-    int s_g[S7C_SLOTS], s_l[S7C_SLOTS], s_py[S7C_SLOTS], s_f[S7C_SLOTS];
+    // (two registers per slot: the global offset and (py, f) packed; the LDS offset is (tid + 256 s) * 16 bytes -- the prefetch registers
+    // share the file with 74 weight / address registers, and a spill reload in the loop would wait for the whole prefetch)
+    int s_g[G::SLOTS], s_pf[G::SLOTS];
 #pragma unroll
-    for (int s = 0; s < S7C_SLOTS; ++s) {
+    for (int s = 0; s < G::SLOTS; ++s) {
         const int idx = tid + s * IG_THREADS;
-        const int pr = idx / (S7C_PW / 4), f = idx - pr * (S7C_PW / 4);
-        const int c = pr / S7C_PH, py = pr - c * S7C_PH;
+        const int pr = idx / (G::PW / 4), f = idx - pr * (G::PW / 4);
+        const int c = pr / G::PH, py = pr - c * G::PH;
         s_g[s] = (c * H + py) * W + f * 4;
-        s_l[s] = idx < S7C_F4 ? idx * 4 : -1;
-        s_py[s] = py; s_f[s] = f * 4;
+        s_pf[s] = py | (f << 10);
     }
-    float4 v[S7C_SLOTS];
+    float4 v[G::SLOTS];
     auto load_window = [&](int tl) {
         const int tx = tl % tilesX, r_ = tl / tilesX;
         const int ty = r_ % tilesY, b = r_ / tilesY;
-        const int iy0 = ty * S7C_TH - 3, ix0 = tx * S7C_TW - 4;
+        const int iy0 = ty * G::TH * S - 3, ix0 = tx * G::TW * S - 4;
         const float* xb = x + ((long long)b * 3 * H + iy0) * W + ix0;            // scalar; may point before the image (never loaded from)
 #pragma unroll
-        for (int s = 0; s < S7C_SLOTS; ++s) {
-            const int yy = iy0 + s_py[s], xx = ix0 + s_f[s];
+        for (int s = 0; s < G::SLOTS; ++s) {
+            const int yy = iy0 + (s_pf[s] & 1023), xx = ix0 + (s_pf[s] >> 10) * 4;
+            const bool in = (s + 1) * IG_THREADS <= G::F4 || tid + s * IG_THREADS < G::F4;
             v[s] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (s_l[s] >= 0 && yy >= 0 && yy < H && xx >= 0 && xx < W) v[s] = ig_ldg4(xb + s_g[s]);      // W % 4 == 0: a quad is in or out
+            if (in && yy >= 0 && yy < H && xx >= 0 && xx < W) v[s] = ig_ldg4(xb + s_g[s]);      // W % 4 == 0: a quad is in or out
         }
     };
     auto store_window = [&]() {
 #pragma unroll
-        for (int s = 0; s < S7C_SLOTS; ++s)
-            if (s_l[s] >= 0) *reinterpret_cast<float4*>(patch + s_l[s]) = v[s];
+        for (int s = 0; s < G::SLOTS; ++s)
+            if ((s + 1) * IG_THREADS <= G::F4 || tid + s * IG_THREADS < G::F4) *reinterpret_cast<float4*>(patch + (tid + s * IG_THREADS) * 4) = v[s];
     };
 
     int tl = slot;
     if (tl < ntiles) load_window(tl);
-    // A operand (weights): row n = j, k = 4m + g = (c*7 + ky)*7 + kx, read from the [16][176] pack (k' = (c*7 + ky)*8 + kx); zero for k >= 147.
-    // B operand address of MFMA m: window float (c*PH + ky) * PW + kx + 1 (+ this wave's first row, + pixel j)
+    // A operand (weights): row n = 16 nset + j, k = 4m + g = (c*7 + ky)*7 + kx, read from the [NOUT][176] pack (k' = (c*7 + ky)*8 + kx); zero for
+    // k >= 147.  B operand address of MFMA m: window float (c*PH + ky) * PW + kx + 1 (+ S * (this wave's first row), + S * pixel j)
     float wr[37];
     int ba[37];
 #pragma unroll
@@ -178,11 +192,11 @@ __global__ __launch_bounds__(IG_THREADS, 3) void stem7x7_c16_kernel(const float*
         const int row = k / 7, kx = k - row * 7;           // row = c*7 + ky
         const int c = row / 7, ky = row - c * 7;
         const bool kok = k < 147;
-        wr[m] = kok ? w[j * S7_K + row * 8 + kx] : 0.f;
-        ba[m] = kok ? ((c * S7C_PH + ky + wid * (S7C_TH / 4)) * S7C_PW + kx + 1 + j) : j;
+        wr[m] = kok ? w[(nset * 16 + j) * S7_K + row * 8 + kx] : 0.f;
+        ba[m] = kok ? ((c * G::PH + ky + S * wrow) * G::PW + kx + 1 + S * j) : S * j;
     }
-    const s7_v4 sc = *reinterpret_cast<const s7_v4*>(scale + g * 4), sh = *reinterpret_cast<const s7_v4*>(shift + g * 4);
-    const long long orow = (long long)W * outLd;
+    const s7_v4 sc = *reinterpret_cast<const s7_v4*>(scale + nset * 16 + g * 4), sh = *reinterpret_cast<const s7_v4*>(shift + nset * 16 + g * 4);
+    const long long orow = (long long)Wo * outLd;
     if (tl < ntiles) store_window();
     __syncthreads();
 
@@ -191,15 +205,15 @@ __global__ __launch_bounds__(IG_THREADS, 3) void stem7x7_c16_kernel(const float*
         if (nxt < ntiles) load_window(nxt);
         const int tx = tl % tilesX, r_ = tl / tilesX;
         const int ty = r_ % tilesY, b = r_ / tilesY;
-        const int oyw = ty * S7C_TH + wid * (S7C_TH / 4), oxl = tx * S7C_TW + j;
-        float* const obase = out + ((long long)(b * H + oyw) * W + oxl) * outLd + g * 4;
+        const int oyw = ty * G::TH + wrow, oxl = tx * G::TW + j;
+        float* const obase = out + ((long long)(b * Ho + oyw) * Wo + oxl) * outLd + nset * 16 + g * 4;
 #pragma unroll
-        for (int r = 0; r < S7C_TH / 4; ++r) {             // one output row = four 16-pixel tiles multiplied together
+        for (int r = 0; r < G::RW; ++r) {                  // one output row = four 16-pixel tiles multiplied together
             f32x4 acc[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             float fr[2][4];
-#define S7C_READ(buf, m) _Pragma("unroll") for (int i = 0; i < 4; ++i) fr[buf][i] = patch[ba[m] + r * S7C_PW + i * 16];
+#define S7C_READ(buf, m) _Pragma("unroll") for (int i = 0; i < 4; ++i) fr[buf][i] = patch[ba[m] + S * r * G::PW + S * i * 16];
             S7C_READ(0, 0)
 #pragma unroll
             for (int m = 0; m < 37; ++m) {
@@ -210,10 +224,10 @@ __global__ __launch_bounds__(IG_THREADS, 3) void stem7x7_c16_kernel(const float*
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[m], fr[cb][i], acc[i], 0, 0, 0);
             }
 #undef S7C_READ
-            if (oyw + r < H) {
+            if (oyw + r < Ho) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    if (oxl + i * 16 >= W) continue;
+                    if (oxl + i * 16 >= Wo) continue;
                     s7_v4 o = {acc[i][0], acc[i][1], acc[i][2], acc[i][3]};
                     o = __builtin_elementwise_fma(o, sc, sh);
                     if (relu) o = (s7_v4){fmaxf(o.x, 0.f), fmaxf(o.y, 0.f), fmaxf(o.z, 0.f), fmaxf(o.w, 0.f)};
@@ -229,17 +243,19 @@ __global__ __launch_bounds__(IG_THREADS, 3) void stem7x7_c16_kernel(const float*
     }
 }
 
+template <int NOUT, int S>
 static int launch_stem_c16(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H, int W,
                            int outLd, int relu, hipStream_t s)
 {
-    const int tilesX = cp_cdiv(W, S7C_TW), tilesY = cp_cdiv(H, S7C_TH);
+    typedef S7C<NOUT, S> G;
+    const int Ho = (H + 6 - 7) / S + 1, Wo = (W + 6 - 7) / S + 1;
+    const int tilesX = cp_cdiv(Wo, G::TW), tilesY = cp_cdiv(Ho, G::TH);
     const long long ntiles = (long long)B * tilesX * tilesY;
     if (ntiles >= (1ll << 31)) { cp_set_error("stem7x7: %lld tiles", ntiles); return 1; }
-    const int ncu = cp_num_cus();
-    const long long cap = (long long)ncu * 3;
-    hipLaunchKernelGGL(stem7x7_c16_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(IG_THREADS), 0, s, x, w, scale, shift, out, B, H, W,
-                       outLd, relu, tilesX, tilesY, (int)ntiles);
-    cp_note_kernel("stem7x7_c16_kernel");
+    const long long cap = (long long)cp_num_cus() * G::OCC;
+    hipLaunchKernelGGL((stem7x7_c16_kernel<NOUT, S>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(IG_THREADS), 0, s, x, w, scale, shift, out,
+                       B, H, W, Ho, Wo, outLd, relu, tilesX, tilesY, (int)ntiles);
+    cp_note_kernel("stem7x7_c16_kernel<%d, %d>", NOUT, S);
     return 0;
 }
 
@@ -273,9 +289,10 @@ extern "C" int cp_stem7x7_f32(const float* x, const float* w, const float* scale
     hipStream_t s = (hipStream_t)stream;
     int rc;
     // the persistent kernel needs whole float4 quads inside / outside the image and aligned rows / stores
-    const bool c16 = Cout == 16 && stride == 1 && W % 4 == 0 && outLd % 4 == 0 && (long long)B * 3 * H * W < (1ll << 31) &&
-                     (((size_t)x | (size_t)out | (size_t)scale | (size_t)shift) & 15) == 0;
-    if (c16) rc = launch_stem_c16(x, w, scale, shift, out, B, H, W, outLd, relu, s);
+    const bool pers = W % 4 == 0 && outLd % 4 == 0 && (long long)B * 3 * H * W < (1ll << 31) &&
+                      (((size_t)x | (size_t)out | (size_t)scale | (size_t)shift) & 15) == 0;
+    if (pers && Cout == 16 && stride == 1) rc = launch_stem_c16<16, 1>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
+    else if (pers && Cout == 64 && stride == 2) rc = launch_stem_c16<64, 2>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
     else if (Cout == 16 && stride == 1) rc = launch_stem<16, 1, 8, 64>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
     else if (Cout == 64 && stride == 2) rc = launch_stem<64, 2, 8, 32>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
     else if (Cout == 64 && stride == 1) rc = launch_stem<64, 1, 8, 32>(x, w, scale, shift, out, B, H, W, outLd, relu, s);

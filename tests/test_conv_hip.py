@@ -820,7 +820,8 @@ def test_conv3x3_winograd24_fuzz_vs_direct_kernel():
 
 
 @pytest.mark.parametrize("cout,s,hw", [(16, 1, (40, 72)), (64, 2, (37, 70)), (16, 1, (512, 512)), (64, 2, (128, 96)), (16, 1, (37, 52)),
-                                       (16, 1, (13, 50)), (16, 1, (3, 4)), (16, 1, (70, 200))])
+                                       (16, 1, (13, 50)), (16, 1, (3, 4)), (16, 1, (70, 200)), (64, 2, (512, 512)), (64, 2, (61, 132)),
+                                       (64, 2, (5, 8)), (64, 1, (20, 24)), (16, 2, (20, 24))])
 def test_stem7x7_kernel(cout, s, hw):
     """dedicated 7x7 stem (pose_dla_dcn.py:228-232 / msra_resnet.py:118-121) vs torch-CPU."""
     from centerpose_amd import ops
@@ -833,6 +834,7 @@ def test_stem7x7_kernel(cout, s, hw):
     out = torch.full((2, ref.shape[2], ref.shape[3], cout), float("nan"), device="cuda")
     ops.stem7x7(x.cuda(), ops.pack_stem7_weight(w.cuda()), sc, sh, out, s)
     from centerpose_amd import _lib
-    # 16 outputs / stride 1 with whole float4 quads per row: the persistent weights-in-registers kernel; everything else the LDS-weights one
-    assert _lib.lib().cp_last_kernel().decode().startswith("stem7x7_c16_kernel" if cout == 16 and s == 1 and hw[1] % 4 == 0 else "stem7x7_kernel<")
+    # 16 outputs / stride 1 (DLA) and 64 / stride 2 (ResNet) with whole float4 quads per row: the persistent weights-in-registers kernel;
+    # everything else the LDS-weights one
+    assert _lib.lib().cp_last_kernel().decode().startswith("stem7x7_c16_kernel" if (cout, s) in ((16, 1), (64, 2)) and hw[1] % 4 == 0 else "stem7x7_kernel<")
     _close(out.permute(0, 3, 1, 2), ref)
