@@ -17,30 +17,6 @@ def main(db, out=None):
         lines.append("| `%s` | %d | %.3f | %.1f | %.1f | %.1f | %.1f |" % (n, cnt, s / 1e6, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
     lines.append("")
     lines.append("total kernel time: %.3f ms over %d dispatches" % (tot / 1e6, sum(r[1] for r in rows)))
-    # GPU idle time inside the bursts of dispatches (a burst ends at a pause above 50 us: the host-side gap between steps): the span of
-    # each burst minus the union of its kernel intervals.  Kernels of consecutive graph nodes overlap by a few us (the next one's waves
-    # start while the previous one drains), so summing positive start-to-end gaps would overstate the idle time.
-    ev = c.execute("select start, end from kernels order by start").fetchall()
-    span = busy = 0
-    cur_s = cur_e = None
-    burst_s = None
-    for st, en in ev:
-        if cur_e is None or st - cur_e > 50000:
-            if cur_e is not None:
-                busy += cur_e - cur_s
-                span += cur_e - burst_s
-            burst_s, cur_s, cur_e = st, st, en
-        elif st > cur_e:
-            busy += cur_e - cur_s
-            cur_s, cur_e = st, en
-        else:
-            cur_e = max(cur_e, en)
-    if cur_e is not None:
-        busy += cur_e - cur_s
-        span += cur_e - burst_s
-    if span:
-        lines.append("GPU busy (union of kernel intervals) inside the dispatch bursts: %.3f of %.3f ms = %.2f %% (idle %.3f ms)"
-                     % (busy / 1e6, span / 1e6, 100.0 * busy / span, (span - busy) / 1e6))
     txt = "\n".join(lines)
     if out:
         open(out, "w").write(txt + "\n")
