@@ -309,6 +309,14 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
                      "conv2d: nsub=4 is the fused k4/s2/p1 deconvolution (2x2 taps, output stride 2)");
         CP_CHECK_ARG(tile == 0 || tile > 1000, "conv2d: nsub needs the generic kernel");
     }
+    if (d->inNCHW && tile == 0) {                                      // 3-channel 3x3 / stride 2 stem with 64 outputs (stem7x7.hip)
+        const int prc = cp_launch_stem3x3(a, s);
+        if (prc >= 0) {
+            if (prc) return prc;
+            CP_CHECK_LAUNCH("stem7x7_c16_kernel");
+            return 0;
+        }
+    }
     if (a.nsub == 1 && a.ksplit == 1 && (tile == 0 || tile == 16)) {   // 16-channel 3x3 (stride 1 / 2): weights-in-registers kernel (conv3x3_c16.hip)
         const int prc = cp_launch_conv3x3_c16(a, d->inNCHW, s);
         if (prc >= 0) {

@@ -65,6 +65,8 @@ struct ConvArgs {
 
 // conv3x3_patch.hip: returns -1 when the shape is not eligible, else 0 / error code
 int cp_launch_conv3x3_patch(const ConvArgs& a, int in_nchw, hipStream_t s, int variant = 0);
+// stem7x7.hip: 3x3 / stride 2 / pad 1 stem on the 3-channel NCHW network input, 64 outputs (persistent weights-in-registers kernel): same convention
+int cp_launch_stem3x3(const ConvArgs& a, hipStream_t s);
 // conv3x3_c16.hip (16 input channels, stride 1 or 2, 16 / 32 outputs): same convention
 int cp_launch_conv3x3_c16(const ConvArgs& a, int in_nchw, hipStream_t s);
 // conv3x3_wino.hip (a.w = Winograd-domain weights): same convention

@@ -122,25 +122,28 @@ __global__ __launch_bounds__(IG_THREADS) void stem7x7_kernel(const float* __rest
 // resnet_dcn.py): 4x64-pixel tiles, a wave owns 16 of the 64 output CHANNELS for all rows (37 weight registers per wave either way);
 // the window's pixels are then read at stride 2 (even / odd LDS banks: conflict-free).
 typedef float s7_v4 __attribute__((ext_vector_type(4)));
-template <int NOUT, int S>
+template <int NOUT, int S, int KS>
 struct S7C {
     static constexpr int TH = NOUT == 16 ? 8 : 4, TW = 64;
-    static constexpr int PH = (TH - 1) * S + 7;                     // window rows per plane
-    static constexpr int PW = ((TW - 1) * S + 1 + 7 + 3) & ~3;      // floats per window row, first column S * ox0 - 4 (16-byte aligned in the image): 72 / 136
+    static constexpr int PAD = KS / 2, CO = 4 - PAD;                // window column of input column S * ox0 - PAD (the window starts 4 columns left of S * ox0)
+    static constexpr int PH = (TH - 1) * S + KS;                    // window rows per plane
+    static constexpr int PW = ((TW - 1) * S + KS + CO + 3) & ~3;    // floats per window row, first column S * ox0 - 4 (16-byte aligned in the image): 72 / 136 / 132
     static constexpr int F4 = 3 * PH * (PW / 4);
     static constexpr int SLOTS = (F4 + IG_THREADS - 1) / IG_THREADS;
     static constexpr int RW = NOUT == 16 ? TH / 4 : TH;             // output rows a wave computes
-    static constexpr int OCC = NOUT == 16 ? 3 : 2;                  // resident blocks per CU (168 / 256 VGPRs: no spills with six prefetch slots)
-    static_assert((NOUT == 16 || NOUT == 64) && (S == 1 || S == 2), "stem shapes");
+    static constexpr int OCC = NOUT == 16 ? 3 : (KS == 3 ? 4 : 2);  // resident blocks per CU (7x7: 168 / 256 VGPRs, no spills with six prefetch slots; 3x3: 96 VGPRs)
+    static constexpr int KTOT = 3 * KS * KS, NM = (KTOT + 3) / 4;   // 147 -> 37 MFMAs per 16 pixels, 27 -> 7
+    static constexpr int KSP = KS == 7 ? 8 : KS;                    // kx pitch of the weight pack: [n][(c*7+ky)*8 + kx] (pack_stem7) / [n][(c*KS+ky)*KS + kx] (generic)
+    static_assert((NOUT == 16 || NOUT == 64) && (S == 1 || S == 2) && (KS == 7 || KS == 3), "stem shapes");
 };
 
-template <int NOUT, int S>
-__global__ __launch_bounds__(IG_THREADS, (S7C<NOUT, S>::OCC)) void stem7x7_c16_kernel(const float* __restrict__ x, const float* __restrict__ w,
+template <int NOUT, int S, int KS>
+__global__ __launch_bounds__(IG_THREADS, (S7C<NOUT, S, KS>::OCC)) void stem7x7_c16_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                       const float* __restrict__ scale, const float* __restrict__ shift,
                                                                       float* __restrict__ out, int B, int H, int W, int Ho, int Wo, int outLd, int relu,
-                                                                      int tilesX, int tilesY, int ntiles)
+                                                                      int tilesX, int tilesY, int ntiles, int kpack)
 {
-    typedef S7C<NOUT, S> G;
+    typedef S7C<NOUT, S, KS> G;
     __shared__ __attribute__((aligned(16))) float patch[3 * G::PH * G::PW];
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(IG_THREADS, (S7C<NOUT, S>::OCC)) void stem7x7_c16_k
     auto load_window = [&](int tl) {
         const int tx = tl % tilesX, r_ = tl / tilesX;
         const int ty = r_ % tilesY, b = r_ / tilesY;
-        const int iy0 = ty * G::TH * S - 3, ix0 = tx * G::TW * S - 4;
+        const int iy0 = ty * G::TH * S - G::PAD, ix0 = tx * G::TW * S - 4;
         const float* xb = x + ((long long)b * 3 * H + iy0) * W + ix0;            // scalar; may point before the image (never loaded from)
 #pragma unroll
         for (int s = 0; s < G::SLOTS; ++s) {
@@ -184,16 +187,16 @@ __global__ __launch_bounds__(IG_THREADS, (S7C<NOUT, S>::OCC)) void stem7x7_c16_k
     if (tl < ntiles) load_window(tl);
     // A operand (weights): row n = 16 nset + j, k = 4m + g = (c*7 + ky)*7 + kx, read from the [NOUT][176] pack (k' = (c*7 + ky)*8 + kx); zero for
     // k >= 147.  B operand address of MFMA m: window float (c*PH + ky) * PW + kx + 1 (+ S * (this wave's first row), + S * pixel j)
-    float wr[37];
-    int ba[37];
+    float wr[G::NM];
+    int ba[G::NM];
 #pragma unroll
-    for (int m = 0; m < 37; ++m) {
+    for (int m = 0; m < G::NM; ++m) {
         const int k = 4 * m + g;
-        const int row = k / 7, kx = k - row * 7;           // row = c*7 + ky
-        const int c = row / 7, ky = row - c * 7;
-        const bool kok = k < 147;
-        wr[m] = kok ? w[(nset * 16 + j) * S7_K + row * 8 + kx] : 0.f;
-        ba[m] = kok ? ((c * G::PH + ky + S * wrow) * G::PW + kx + 1 + S * j) : S * j;
+        const int row = k / KS, kx = k - row * KS;         // row = c*KS + ky
+        const int c = row / KS, ky = row - c * KS;
+        const bool kok = k < G::KTOT;
+        wr[m] = kok ? w[(nset * 16 + j) * kpack + row * G::KSP + kx] : 0.f;
+        ba[m] = kok ? ((c * G::PH + ky + S * wrow) * G::PW + kx + G::CO + S * j) : S * j;
     }
     const s7_v4 sc = *reinterpret_cast<const s7_v4*>(scale + nset * 16 + g * 4), sh = *reinterpret_cast<const s7_v4*>(shift + nset * 16 + g * 4);
     const long long orow = (long long)Wo * outLd;
@@ -216,9 +219,9 @@ __global__ __launch_bounds__(IG_THREADS, (S7C<NOUT, S>::OCC)) void stem7x7_c16_k
 #define S7C_READ(buf, m) _Pragma("unroll") for (int i = 0; i < 4; ++i) fr[buf][i] = patch[ba[m] + S * r * G::PW + S * i * 16];
             S7C_READ(0, 0)
 #pragma unroll
-            for (int m = 0; m < 37; ++m) {
+            for (int m = 0; m < G::NM; ++m) {
                 const int cb = m & 1;
-                if (m + 1 < 37) { S7C_READ(cb ^ 1, m + 1) }
+                if (m + 1 < G::NM) { S7C_READ(cb ^ 1, m + 1) }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[m], fr[cb][i], acc[i], 0, 0, 0);
@@ -243,20 +246,33 @@ __global__ __launch_bounds__(IG_THREADS, (S7C<NOUT, S>::OCC)) void stem7x7_c16_k
     }
 }
 
-template <int NOUT, int S>
-static int launch_stem_c16(const float* x, const float* w, const float* scale, const float* shift, float* out, int B, int H, int W,
+template <int NOUT, int S, int KS>
+static int launch_stem_c16(const float* x, const float* w, int kpack, const float* scale, const float* shift, float* out, int B, int H, int W,
                            int outLd, int relu, hipStream_t s)
 {
-    typedef S7C<NOUT, S> G;
-    const int Ho = (H + 6 - 7) / S + 1, Wo = (W + 6 - 7) / S + 1;
+    typedef S7C<NOUT, S, KS> G;
+    const int Ho = (H + 2 * G::PAD - KS) / S + 1, Wo = (W + 2 * G::PAD - KS) / S + 1;
     const int tilesX = cp_cdiv(Wo, G::TW), tilesY = cp_cdiv(Ho, G::TH);
     const long long ntiles = (long long)B * tilesX * tilesY;
-    if (ntiles >= (1ll << 31)) { cp_set_error("stem7x7: %lld tiles", ntiles); return 1; }
+    if (ntiles >= (1ll << 31)) { cp_set_error("stem: %lld tiles", ntiles); return 1; }
     const long long cap = (long long)cp_num_cus() * G::OCC;
-    hipLaunchKernelGGL((stem7x7_c16_kernel<NOUT, S>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(IG_THREADS), 0, s, x, w, scale, shift, out,
-                       B, H, W, Ho, Wo, outLd, relu, tilesX, tilesY, (int)ntiles);
-    cp_note_kernel("stem7x7_c16_kernel<%d, %d>", NOUT, S);
+    hipLaunchKernelGGL((stem7x7_c16_kernel<NOUT, S, KS>), dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(IG_THREADS), 0, s, x, w, scale, shift, out,
+                       B, H, W, Ho, Wo, outLd, relu, tilesX, tilesY, (int)ntiles, kpack);
+    cp_note_kernel("stem7x7_c16_kernel<%d, %d, %d>", NOUT, S, KS);
     return 0;
+}
+
+// 3x3 / stride 2 / pad 1 stem on the NCHW network input with 64 outputs (HRNet conv1, pose_higher_hrnet.py:283-285): the same persistent kernel
+// with 27 -> 28 = 7 MFMAs per 16 pixels; a.w is the generic stem pack [ldw][K] with k = (c*3 + ky)*3 + kx.  -1 = not this kernel's shape.
+int cp_launch_stem3x3(const ConvArgs& a, hipStream_t s)
+{
+    const bool ok = a.nsrc == 1 && a.srcC[0] == 3 && a.kh == 3 && a.kw == 3 && a.sy == 2 && a.sx == 2 && a.py == 1 && a.px == 1 && a.Cout == 64 &&
+                    a.ldw >= 64 && !a.outNCHW && !a.res && (a.act == CP_ACT_NONE || a.act == CP_ACT_RELU) && a.ksplit == 1 && a.nsub == 1 &&
+                    a.osy == 1 && a.osx == 1 && a.ooy == 0 && a.oox == 0 && a.OH == a.Ho && a.OW == a.Wo &&
+                    a.Ho == (a.H - 1) / 2 + 1 && a.Wo == (a.W - 1) / 2 + 1 && a.W % 4 == 0 && a.outLd % 4 == 0 &&
+                    (long long)a.B * 3 * a.H * a.W < (1ll << 31) && (((size_t)a.src[0] | (size_t)a.out | (size_t)a.scale | (size_t)a.shift) & 15) == 0;
+    if (!ok) return -1;
+    return launch_stem_c16<64, 2, 3>(a.src[0], a.w, a.K, a.scale, a.shift, a.out, a.B, a.H, a.W, a.outLd, a.act == CP_ACT_RELU ? 1 : 0, s);
 }
 
 template <int NOUT, int S, int TH, int TW>
@@ -291,8 +307,8 @@ extern "C" int cp_stem7x7_f32(const float* x, const float* w, const float* scale
     // the persistent kernel needs whole float4 quads inside / outside the image and aligned rows / stores
     const bool pers = W % 4 == 0 && outLd % 4 == 0 && (long long)B * 3 * H * W < (1ll << 31) &&
                       (((size_t)x | (size_t)out | (size_t)scale | (size_t)shift) & 15) == 0;
-    if (pers && Cout == 16 && stride == 1) rc = launch_stem_c16<16, 1>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
-    else if (pers && Cout == 64 && stride == 2) rc = launch_stem_c16<64, 2>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
+    if (pers && Cout == 16 && stride == 1) rc = launch_stem_c16<16, 1, 7>(x, w, S7_K, scale, shift, out, B, H, W, outLd, relu, s);
+    else if (pers && Cout == 64 && stride == 2) rc = launch_stem_c16<64, 2, 7>(x, w, S7_K, scale, shift, out, B, H, W, outLd, relu, s);
     else if (Cout == 16 && stride == 1) rc = launch_stem<16, 1, 8, 64>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
     else if (Cout == 64 && stride == 2) rc = launch_stem<64, 2, 8, 32>(x, w, scale, shift, out, B, H, W, outLd, relu, s);
     else if (Cout == 64 && stride == 1) rc = launch_stem<64, 1, 8, 32>(x, w, scale, shift, out, B, H, W, outLd, relu, s);

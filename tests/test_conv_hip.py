@@ -76,9 +76,11 @@ def test_conv_concat_sources_and_channel_views():
 
 
 @pytest.mark.parametrize("cout,k,s,p,hw,tile", [(16, 7, 1, 3, (40, 36), 0), (64, 7, 2, 3, (37, 41), 0),
-                                                (64, 3, 2, 1, (32, 32), 0), (32, 7, 1, 3, (24, 24), 0)])
+                                                (64, 3, 2, 1, (32, 32), 0), (32, 7, 1, 3, (24, 24), 0), (64, 3, 2, 1, (37, 52), 0),
+                                                (64, 3, 2, 1, (256, 384), 0), (64, 3, 2, 1, (21, 30), 0), (64, 3, 2, 1, (32, 32), 128064)])
 def test_stem_nchw_input(cout, k, s, p, hw, tile):
-    """network input is NCHW float32 with 3 channels (base_detector.py:53-58)."""
+    """network input is NCHW float32 with 3 channels (base_detector.py:53-58).  3x3 / stride 2 / 64 outputs with whole float4 quads per row
+    (HRNet conv1, pose_higher_hrnet.py:283-285) goes to the persistent stem kernel; everything else to the scalar-gather producer."""
     from centerpose_amd import ops
     g = torch.Generator().manual_seed(cout + k)
     x = torch.randn(2, 3, *hw, generator=g)
@@ -89,6 +91,9 @@ def test_stem_nchw_input(cout, k, s, p, hw, tile):
     out = torch.empty(2, ref.shape[2], ref.shape[3], cout, device="cuda")
     ops.conv2d([x.cuda()], ops.pack_conv_weight(w.cuda(), stem=True), sc, sh, out, kh=k, kw=k, stride=s, pad=p,
                cout=cout, act=ops.ACT_RELU, in_nchw=True, tile=tile)
+    from centerpose_amd import _lib
+    pers = (cout, k, s, p) == (64, 3, 2, 1) and hw[1] % 4 == 0 and tile == 0
+    assert _lib.lib().cp_last_kernel().decode().startswith("stem7x7_c16_kernel<64, 2, 3>" if pers else "igemm_conv_kernel")
     _close(out.permute(0, 3, 1, 2), ref)
 
 
