@@ -436,10 +436,12 @@ class PlanBuilder(nets.Graph):
         return outs
 
 
-def list_schedule(deps, durations, nstreams=2):
+def list_schedule(deps, durations, nstreams=2, prefer=None):
     """List scheduling of a DAG on `nstreams` in-order streams.  deps[i] = indices (< i) launch i must follow, durations[i] its
     time.  Priority = b-level (longest path from the launch to the end of the graph); the (ready launch, stream) pair that can
-    start earliest goes next, ties to the higher priority, then to the lower stream.  Returns (order, assign, makespan): `order`
+    start earliest goes next, ties to a launch flagged in `prefer` (light launches that should run BESIDE the big ones as soon as
+    they are ready, not after them: the simulation treats a stream as an exclusive resource and cannot see that difference), then
+    to the higher priority, then to the lower stream.  Returns (order, assign, makespan): `order`
     is a permutation of range(n) that is a topological order (sorted by simulated start time), `assign[i]` the stream of launch
     i, `makespan` the simulated length -- a lower bound of what the GPU does, because concurrent launches share it."""
     n = len(deps)
@@ -460,10 +462,10 @@ def list_schedule(deps, durations, nstreams=2):
         for i in ready:
             est = max([finish[j] for j in deps[i]], default=0.0)
             for p in range(nstreams):
-                key = (max(est, free[p]), -blevel[i], p)
+                key = (max(est, free[p]), 0 if prefer is not None and prefer[i] else 1, -blevel[i], p)
                 if best is None or key < best[0]:
                     best = (key, i, p)
-        (t, _, _), i, p = best
+        (t, _, _, _), i, p = best
         ready.remove(i)
         start[i], finish[i], free[p], assign[i] = t, t + durations[i], t + durations[i], p
         for c in set(children[i]):
@@ -616,7 +618,11 @@ class Engine:
         elif isinstance(durations, str) and durations == "model":
             ll = self.launches if launches is None else launches
             durations = [max(f / 100e12, nb / 4e12) * 1e3 + 5e-3 for (_, _, f, _), nb in zip(ll, self.launch_bytes(ll))]
-        return list_schedule(self.dependencies(launches), durations, nstreams)
+        # the peak extraction (288 small blocks, no MFMA) needs hm / hm_hp only: as soon as those two heads are done it goes beside the
+        # remaining head convolutions instead of behind them (a 56 us tail of the step at B = 16 otherwise)
+        ll = self.launches if launches is None else launches
+        prefer = [kind == "decode.nms_topk" for (_, kind, _, _) in ll] if os.environ.get("CP_SCHED_PREFER", "1") != "0" else None
+        return list_schedule(self.dependencies(launches), durations, nstreams, prefer)
 
     def _run_branches(self, main, nstreams, deps, assign=None):
         """Enqueue the schedule on `nstreams` streams (main + side streams): independent branches of the graph
