@@ -325,6 +325,23 @@ def test_order_is_topological_and_list_schedule():
     assert order_is_topological(deps, bad) and not order_is_topological(deps2, bad)
 
 
+def test_list_schedule_prefers_flagged_light_launch_on_ties():
+    """The head section of the step: feature map -> six head launches -> (peak extraction after two of them) -> assignment after all.
+    Without `prefer` the peak extraction (short remaining path) is placed behind the last head; flagged, it takes the tie at the moment
+    its two heads are done and runs beside the remaining heads.  Either way the order is topological and the simulated span equal."""
+    from centerpose_amd.engine import list_schedule, order_is_topological
+    #        0 feat, 1 hm_hp, 2 hps, 3 hm, 4 wh, 5 reg, 6 hp_offset, 7 nms_topk (needs 1, 3), 8 assign (needs all)
+    deps = [[], [0], [0], [0], [0], [0], [0], [1, 3], [2, 4, 5, 6, 7]]
+    dur = [1.0, 0.314, 0.361, 0.268, 0.27, 0.27, 0.27, 0.056, 0.014]
+    plain, _, span0 = list_schedule(deps, dur, 2)
+    pref, assign, span1 = list_schedule(deps, dur, 2, [i == 7 for i in range(9)])
+    assert order_is_topological(deps, plain) and order_is_topological(deps, pref)
+    assert abs(span0 - span1) < 1e-9
+    assert plain.index(7) == 7 and pref.index(7) < plain.index(7)           # behind every head before; earlier now
+    assert sum(1 for i in (4, 5, 6) if pref.index(i) > pref.index(7)) >= 2   # at least two heads still to run beside it
+    assert pref[-1] == 8 and set(assign) <= {0, 1}
+
+
 def test_resdcn_checkpoint_keys_are_the_standalone_models():
     """`resdcn` (resnet_dcn.py) is a stand-alone PoseResNet: its state_dict has no backbone_model. / head_model. prefixes and its
     heads are attributes (hm.0.weight ...).  The spec / synthetic checkpoint use that spelling; the engine maps it onto the graph's
