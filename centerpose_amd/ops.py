@@ -304,7 +304,8 @@ def head3x3_1x1_launch(x, u, scale, shift, w2, b2, out2, *, hc, act2=ACT_NONE, w
 
 def wino_eligible(cin, k, stride, pad, nsrc=1):
     """3x3 / stride 1 / pad 1 single-source NHWC layers with >= 32 input channels go through the Winograd kernel
-    (16-channel layers stay on the direct patch kernel: measured 0.36 vs 0.24 ms for DLA level0)."""
+    (16-channel layers stay on a direct kernel -- measured 0.36 vs 0.24 ms for DLA level0 in round 1; since round 4 that is the persistent
+    weights-in-registers kernel conv3x3_c16.hip at 0.165 ms)."""
     return k == 3 and stride == 1 and pad == 1 and nsrc == 1 and cin % 16 == 0 and cin >= 32
 
 
