@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the res_50 B=8 / hrnet B=8 evidence runs after the timed region")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)      # internal: one worker of cpu_baseline's multi-process layouts
+    ap.add_argument("--force-gather", action="store_true",
+                    help="N = 1: create a process group of ONE rank (RCCL on the GPU box) and run the step's all-gather through it on "
+                         "the side stream exactly as at N > 1 -- everything of the multi-GPU path except the xGMI wire")
     ap.add_argument("--gather-check", action="store_true",
                     help="N > 1: after the timed region compare every rank's gathered dets (checksum exchange) and its own shard's slot")
     return ap.parse_args()
@@ -329,7 +332,8 @@ def main():
     from centerpose_amd import engine, synth
     from centerpose_amd.decode import multi_pose_decode
 
-    rank, world, local = cpd.init_from_env()
+    rank, world, local = cpd.init_from_env(force=args.force_gather)
+    grouped = world > 1 or args.force_gather        # a process group exists (world 1 only under --force-gather)
     assert world == args.gpus, "WORLD_SIZE=%d but --gpus %d" % (world, args.gpus)
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     local = local % torch.cuda.device_count()     # (lets a 1-GPU box smoke-test the N>1 control flow over gloo)
@@ -343,7 +347,7 @@ def main():
     lo, _ = cpd.shard_range(B * world, rank, world)
     images = synth.make_images(B, seed=317 + lo).to(dev)      # this rank's shard, resident in HBM
     eng.input.copy_(images)
-    gat = cpd.DetsGatherer(global_batch=B * world, time_waits=True)
+    gat = cpd.DetsGatherer(global_batch=B * world, time_waits=True, force=args.force_gather)
 
     def step():
         """one batch through backbone + heads + decode; the all-gather of its detections is left running on the side
@@ -358,7 +362,7 @@ def main():
     if gat.pending:
         gat.collect()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     torch.cuda.synchronize()
@@ -369,13 +373,13 @@ def main():
         marks[i + 1].record()
     out = gat.collect()                              # the last step's gather is inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     rank_ms = {"min": elapsed / args.steps * 1e3, "max": elapsed / args.steps * 1e3}
     wait_total, wait_max = gat.exposed_wait_ms()
     gather_info = None
-    if world > 1:
+    if grouped:
         cdev = dev if dist.get_backend() == "nccl" else "cpu"
         own = torch.tensor([elapsed, wait_total, wait_max], dtype=torch.float64, device=cdev)
         hi, lo = own.clone(), own.clone()
@@ -392,7 +396,7 @@ def main():
                                      else "not timed (host-staged gloo gather is synchronous)"}
         if args.gather_check:
             _, last = eng.process(eng.input)
-            ok, _, msg = cpd.check_gathered(cpd.gather_dets(last.clone(), B * world), last, B * world)
+            ok, _, msg = cpd.check_gathered(cpd.gather_dets(last.clone(), B * world, force=args.force_gather), last, B * world)
             gather_info["check"] = msg
             assert ok, msg
     assert out.shape == (B * world, 100, 56)
@@ -410,8 +414,8 @@ def main():
                                        "decode%s" % (args.arch, B, ", RCCL all-gather of decoded poses (side stream)" if world > 1 else ""),
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
                            "weights": "seeded synthetic checkpoint (reference key layout)"},
-                "ranks": dist.get_world_size() if world > 1 else 1,
-                "backend": dist.get_backend() if world > 1 else None,
+                "ranks": dist.get_world_size() if grouped else 1,
+                "backend": dist.get_backend() if grouped else None,
                 "rank_ms_per_step": {k: round(v, 3) for k, v in rank_ms.items()},
                 "gather": gather_info,
                 "graph_capture": eng.capture_mode if not args.no_graph else "eager",
@@ -440,7 +444,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -246,6 +246,36 @@ extern "C" int cp_nhwc_to_nchw_f32(const float* in, int inLd, int cOff, float* o
     return 0;
 }
 
+// Kernel-side constants of a DCNv2 (weight, bias) pair in ONE launch: w [Co][C][kh*kw] (the reference's nn.Parameter layout,
+// DCNv2/dcn_v2.py:99-103) -> wp [ldw][kh*kw*Cp] with k = (tap * dg + g) * cpgp + c (every deformable group padded from cpg to cpgp
+// channels), zero rows / columns for the padding; scale = 1, shift = bias for n < Co, 0 above.  A few microseconds for the
+// reference's layers, so the drop-in dcn_v2_forward faces pack on EVERY call instead of caching packed weights on tensor identity
+// (`.data` edits do not bump a parameter's version counter; a cache keyed on it silently convolves with stale weights).
+__global__ void dcn_pack_kernel(const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ wp, float* __restrict__ scale,
+                                float* __restrict__ shift, int Co, int C, int kk, int dg, int cpg, int cpgp, int ldw)
+{
+    const int Kp = kk * dg * cpgp;
+    const long long total = (long long)ldw * Kp;
+    for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+        const int n = (int)(i / Kp), k = (int)(i - (long long)n * Kp);
+        const int c = k % cpgp, tg = k / cpgp, g = tg % dg, tap = tg / dg;
+        wp[i] = (n < Co && c < cpg) ? w[((size_t)n * C + g * cpg + c) * kk + tap] : 0.f;
+        if (k == 0) { scale[n] = n < Co ? 1.f : 0.f; shift[n] = n < Co ? bias[n] : 0.f; }
+    }
+}
+extern "C" int cp_dcn_pack_weights_f32(const float* w, const float* bias, int Co, int C, int kh, int kw, int dg, int Cp, int ldw, float* wp,
+                                       float* scale, float* shift, void* stream)
+{
+    CP_CHECK_ARG(w && bias && wp && scale && shift, "dcn_pack_weights: null pointer");
+    CP_CHECK_ARG(dg >= 1 && C % dg == 0 && Cp % dg == 0 && Cp / dg >= C / dg && (Cp / dg) % 16 == 0 && ldw >= Co && kh * kw >= 1,
+                 "dcn_pack_weights: C=%d dg=%d Cp=%d Co=%d ldw=%d", C, dg, Cp, Co, ldw);
+    const long long total = (long long)ldw * kh * kw * Cp;
+    hipLaunchKernelGGL(dcn_pack_kernel, dim3(ew_grid(total)), dim3(EW_THREADS), 0, (hipStream_t)stream, w, bias, wp, scale, shift, Co, C,
+                       kh * kw, dg, C / dg, Cp / dg, ldw);
+    CP_CHECK_LAUNCH("dcn_pack_kernel");
+    return 0;
+}
+
 extern "C" int cp_fill_f32(float* p, float v, long long n, void* stream);
 __global__ void fill_kernel(float* p, float v, long long n)
 {

@@ -6,16 +6,13 @@
 //     dcn_v2_forward(input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, deformable_group) -> Tensor
 //         identical 14-argument signature (src/dcn_v2.h:9-23); fp32 contiguous NCHW HIP tensors in, a NEW NCHW tensor out
 //         (at::empty, dcn_v2_cuda.cu:91); CPU tensors raise like AT_ERROR("Not implemented on the CPU") (cpu/dcn_v2_cpu.cpp:7-24)
-//         any deformable_group (dcn_v2_im2col_cuda.cu:153,162-164); packed weights cached on (data_ptr, _version)
+//         any deformable_group (dcn_v2_im2col_cuda.cu:153,162-164); weights packed by one device launch per call (no cache)
+//     dcn_v2_psroi_pooling_forward / _backward (vision.cpp:8-9): present, raise -- no centerpose model calls them
 //     multi_pose_decode(heat, wh, kps, reg?, hm_hp?, hp_offset?, K, return_indices=False) -> Tensor[B,K,5+3J]  (lib/models/decode.py:235-308)
 //     plan_create_from_state_dict(arch, state_dict, B, H, W, head_conv=None, use_graph=True) -> handle       
 //     plan_create(path, use_graph) -> handle; plan_forward(handle, images) -> 6 tensors; plan_process(handle, images, K) -> dets;
 //     plan_destroy(handle)                                                                      (lib/models/model.py:57-59)
 // Kernels are enqueued on the current HIP stream of the input's device; nothing synchronises the host.
-#include <map>
-#include <mutex>
-#include <tuple>
-
 #include <torch/extension.h>
 #include <c10/hip/HIPStream.h>
 
@@ -42,53 +39,30 @@ at::Tensor nhwc_from_nchw(const at::Tensor& x, int Cpad, int c_off, at::Tensor o
 }
 
 // Kernel-side constants of one (weight, bias) pair: packed [ldw][kh*kw*Cp] weights (k = (ky*kw + kx)*Cp + c, every deformable group
-// padded to a multiple of 16 channels), scale = 1, shift = bias.  The reference's DCN module passes the same parameters on every
-// forward (DCNv2/dcn_v2.py:117-127); re-packing them per call cost more than the convolution, so the result is cached
-// on (data_ptr, _version) of both tensors.  An in-place update of a parameter bumps its version: the entry is rebuilt.
+// padded to a multiple of 16 channels), scale = 1, shift = bias -- ONE device launch (cp_dcn_pack_weights_f32, a few microseconds)
+// on the caller's stream, on EVERY call.  Rounds 3-4 cached the result on (data_ptr, _version) of the parameters; `.data` edits
+// (w.data.copy_(), EMA / legacy loaders, the reference's own reset_parameters, DCNv2/dcn_v2.py:44-52) do not bump the version
+// counter, _version() raises on inference tensors, and a pack built on one stream was read by others without an event.
+// No cache: nothing to go stale, nothing shared between streams.
 struct PackedDcn {
     at::Tensor wp, scale, shift;
     int ldw, Cp;
-    // a freed parameter's address can be handed to a NEW tensor with the same version counter: an entry only counts while the
-    // TensorImpls it was built from are alive and are the ones passed in
-    c10::weak_intrusive_ptr<c10::TensorImpl> wimpl{c10::intrusive_ptr<c10::TensorImpl>()}, bimpl{c10::intrusive_ptr<c10::TensorImpl>()};
 };
-struct PackedKey {
-    const void *w, *b;
-    int64_t wv, bv;
-    int dg, dev;
-    bool operator<(const PackedKey& o) const { return std::tie(w, b, wv, bv, dg, dev) < std::tie(o.w, o.b, o.wv, o.bv, o.dg, o.dev); }
-};
-// heap-allocated and never destroyed: the entries own device tensors, and a static destructor would release them after the HIP runtime
-// has shut down at interpreter exit
-std::map<PackedKey, PackedDcn>& g_packed = *new std::map<PackedKey, PackedDcn>();
-std::mutex g_packed_mu;
 
 PackedDcn packed_dcn_weights(const at::Tensor& weight, const at::Tensor& bias, int dg)
 {
-    const PackedKey key{weight.data_ptr(), bias.data_ptr(), (int64_t)weight._version(), (int64_t)bias._version(), dg, (int)weight.get_device()};
-    std::lock_guard<std::mutex> lock(g_packed_mu);
-    auto it = g_packed.find(key);
-    if (it != g_packed.end()) {
-        const auto w = it->second.wimpl.lock(), b = it->second.bimpl.lock();
-        if (w.get() == weight.unsafeGetTensorImpl() && b.get() == bias.unsafeGetTensorImpl()) return it->second;
-        g_packed.erase(it);
-    }
     const int Co = weight.size(0), C = weight.size(1), kh = weight.size(2), kw = weight.size(3), kk = kh * kw;
-    const int cpg = C / dg, cpgp = (cpg + 15) / 16 * 16, Cp = dg * cpgp, Cop = Co > 17 ? Co : 17;
-    const auto opt = weight.options();
+    const int cpg = C / dg, cpgp = (cpg + 15) / 16 * 16, Cop = Co > 17 ? Co : 17;
+    const auto opt = weight.options().requires_grad(false);
     PackedDcn r;
-    r.Cp = Cp;
+    r.Cp = dg * cpgp;
     r.ldw = Cop <= 32 ? 32 : (Cop + 63) / 64 * 64;          // Cout padded to the kernel's N tile
-    r.wp = at::zeros({r.ldw, kk * Cp}, opt);
-    r.wp.view({r.ldw, kk, dg, cpgp}).slice(0, 0, Co).slice(3, 0, cpg).copy_(weight.reshape({Co, dg, cpg, kk}).permute({0, 3, 1, 2}));
-    r.scale = at::zeros({r.ldw}, opt);
-    r.shift = at::zeros({r.ldw}, opt);
-    r.scale.slice(0, 0, Co).fill_(1.0f);
-    r.shift.slice(0, 0, Co).copy_(bias);
-    r.wimpl = c10::weak_intrusive_ptr<c10::TensorImpl>(weight.getIntrusivePtr());
-    r.bimpl = c10::weak_intrusive_ptr<c10::TensorImpl>(bias.getIntrusivePtr());
-    if (g_packed.size() >= 64) g_packed.clear();
-    g_packed[key] = r;
+    r.wp = at::empty({r.ldw, kk * r.Cp}, opt);
+    r.scale = at::empty({r.ldw}, opt);
+    r.shift = at::empty({r.ldw}, opt);
+    const auto w = weight.detach().contiguous(), b = bias.detach().contiguous();
+    CP_CALL(cp_dcn_pack_weights_f32(w.data_ptr<float>(), b.data_ptr<float>(), Co, C, kh, kw, dg, r.Cp, r.ldw, r.wp.data_ptr<float>(),
+                                    r.scale.data_ptr<float>(), r.shift.data_ptr<float>(), cur_stream(weight)), "cp_dcn_pack_weights_f32");
     return r;
 }
 
@@ -138,10 +112,22 @@ at::Tensor dcn_v2_forward(const at::Tensor& input, const at::Tensor& weight, con
     return out;
 }
 
-std::vector<at::Tensor> dcn_v2_backward(const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&, const at::Tensor&,
-                                        const at::Tensor&, int, int, int, int, int, int, int, int, int)
+py::object dcn_v2_backward(const py::args&, const py::kwargs&)         // src/dcn_v2.h:25-39 (15 arguments; never evaluated)
 {
     TORCH_CHECK(false, "dcn_v2_backward: training is out of scope of the MI355X inference hot path");
+}
+
+// DCNv2/src/vision.cpp:8-9 exports two more names (deformable PS-RoI pooling, src/dcn_v2.h:41-95).  No centerpose model reaches
+// them (out of scope); they exist so that an attribute lookup on the drop-in module fails with the same clear message
+// as dcn_v2_backward instead of an AttributeError.
+py::object dcn_v2_psroi_pooling_forward(const py::args&, const py::kwargs&)
+{
+    TORCH_CHECK(false, "dcn_v2_psroi_pooling_forward: deformable PS-RoI pooling is not part of the MI355X inference hot path "
+                       "(no centerpose model calls it: DCNv2/dcn_v2.py:130-303 is used by none of lib/models/backbones)");
+}
+py::object dcn_v2_psroi_pooling_backward(const py::args&, const py::kwargs&)
+{
+    TORCH_CHECK(false, "dcn_v2_psroi_pooling_backward: training is out of scope of the MI355X inference hot path");
 }
 
 // return_indices: also (inds [B,K] int32 = centre indices, hm_inds [B,J,K] int32 = joint-candidate indices, scores [B,1+J,K]) --
@@ -235,6 +221,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.def("dcn_v2_forward", &dcn_v2_forward, "dcn_v2_forward");       // DCNv2/src/vision.cpp:6
     m.def("dcn_v2_backward", &dcn_v2_backward, "dcn_v2_backward");    // :7 (raises: inference only)
+    m.def("dcn_v2_psroi_pooling_forward", &dcn_v2_psroi_pooling_forward, "dcn_v2_psroi_pooling_forward");      // :8 (raises)
+    m.def("dcn_v2_psroi_pooling_backward", &dcn_v2_psroi_pooling_backward, "dcn_v2_psroi_pooling_backward");   // :9 (raises)
     m.def("multi_pose_decode", &multi_pose_decode, py::arg("heat"), py::arg("wh"), py::arg("kps"), py::arg("reg") = py::none(),
           py::arg("hm_hp") = py::none(), py::arg("hp_offset") = py::none(), py::arg("K") = 100, py::arg("return_indices") = false);
     m.def("plan_create", &plan_create, py::arg("path"), py::arg("use_graph") = true);

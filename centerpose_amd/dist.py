@@ -10,15 +10,22 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend=None):
+def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
-    Returns (rank, world_size, local_rank); a no-op single-process answer when WORLD_SIZE is unset."""
+    Returns (rank, world_size, local_rank); a no-op single-process answer when WORLD_SIZE is unset -- unless `force`:
+    then a process group of world size 1 is created all the same (rendezvous on a free 127.0.0.1 port), so that the
+    collective of `DetsGatherer(force=True)` really goes through RCCL on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
+    if world == 1 and not force:
         return 0, 1, 0
-    rank, local = int(os.environ["RANK"]), int(os.environ.get("LOCAL_RANK", "0"))
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if "MASTER_PORT" not in os.environ:            # (only the forced single-process group gets here without a launcher)
+            import socket
+            with socket.socket() as s:
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = os.environ.get("CP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -46,16 +53,17 @@ def _shard_sizes(dets, global_batch, world):
     return [int(s.item()) for s in sizes]
 
 
-def gather_dets(dets, global_batch=None):
+def gather_dets(dets, global_batch=None, force=False):
     """All-gather detections along the batch axis: [B_local,K,D] -> [sum B_local, K, D] on every rank.
     Equal shard sizes use one all_gather_into_tensor (a single RCCL launch); ragged shards fall back
-    to a padded gather.  `global_batch`: the step's global batch when sharded with `shard_range` (no size exchange)."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size() == 1:
+    to a padded gather.  `global_batch`: the step's global batch when sharded with `shard_range` (no size exchange).
+    `force`: issue the collective even in a world of one rank (the one-GPU RCCL test; default: pass-through)."""
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size() == 1 and not force):
         return dets
     world = dist.get_world_size()
     backend = dist.get_backend()
     if backend == "gloo" and dets.is_cuda:       # gloo has no CUDA all_gather: stage through the host (tests only)
-        return gather_dets(dets.cpu(), global_batch).to(dets.device)
+        return gather_dets(dets.cpu(), global_batch, force).to(dets.device)
     sizes = _shard_sizes(dets, global_batch, world)
     if len(set(sizes)) == 1 and backend == "nccl":
         out = torch.empty((world * dets.shape[0],) + tuple(dets.shape[1:]), dtype=dets.dtype, device=dets.device)
@@ -74,14 +82,18 @@ class DetsGatherer:
     """The step's one collective on a SIDE stream: `submit(dets)` enqueues the all-gather of this step's
     detections behind the decode that produced them and returns at once, so the next batch's backbone replay overlaps the
     (latency-bound, ~358 KB per rank) exchange over xGMI; `collect()` makes the current stream wait for the oldest
-    outstanding gather and returns its [B_global, K, D] tensor.  One step of pipelining; world 1 is a pass-through.
+    outstanding gather and returns its [B_global, K, D] tensor.  One step of pipelining; world 1 is a pass-through unless
+    `force` (then the same RCCL launch / side stream / events run in a process group of one rank).
     `submit` must be given a tensor the producer will NOT overwrite before `collect` (the exchange reads it asynchronously):
     `MultiPoseDetector.process` / `BackBoneWithHead.process` return such a private copy; a raw `Engine.dets` buffer must be
     cloned first (bench.py does).  `exposed_wait_ms()` reports how long the `collect` calls left the compute stream waiting (total, worst)."""
 
-    def __init__(self, global_batch=None, time_waits=False):
+    def __init__(self, global_batch=None, time_waits=False, force=False):
         self.global_batch = global_batch
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        # force: treat an initialised process group of ONE rank like any other world (the collective, the side stream and the
+        # event ordering all run; only the wire is missing) -- how RCCL is exercised on a one-GPU box
+        self.force = force
+        self.active = dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force)
         self.side = torch.cuda.Stream() if self.active and torch.cuda.is_available() and dist.get_backend() == "nccl" else None
         self.pending = []
         # time_waits: bracket every collect()'s wait with two events on the compute stream -> `exposed_wait_ms()`: the time
@@ -91,12 +103,12 @@ class DetsGatherer:
 
     def submit(self, dets):
         if self.side is None:
-            self.pending.append((gather_dets(dets, self.global_batch) if self.active else dets, None))
+            self.pending.append((gather_dets(dets, self.global_batch, self.force) if self.active else dets, None))
             return
         self.side.wait_stream(torch.cuda.current_stream())
         dets.record_stream(self.side)
         with torch.cuda.stream(self.side):
-            out = gather_dets(dets, self.global_batch)
+            out = gather_dets(dets, self.global_batch, self.force)
             done = torch.cuda.Event()
             done.record(self.side)
         self.pending.append((out, done))

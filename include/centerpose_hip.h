@@ -121,6 +121,12 @@ typedef struct cp_dcn_desc {
 } cp_dcn_desc;
 int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* om, const float* w, const float* scale,
                   const float* shift, float* out, void* stream);
+/* Kernel-side constants of a DCNv2 layer from the reference's parameters, one launch: w [Co][C][kh][kw] and bias [Co]
+ * (nn.Parameter layout, DCNv2/dcn_v2.py:99-103) -> wp [ldw][kh*kw*Cp] (k = (tap*dg + g)*(Cp/dg) + c, zero padding), scale [ldw] = 1,
+ * shift [ldw] = bias -- the `w`, `scale`, `shift` of cp_dcn_v2_f32.  The drop-in dcn_v2_forward (DCNv2/src/dcn_v2.h:9-23) calls it
+ * on every forward: no packed-weight cache to go stale. */
+int cp_dcn_pack_weights_f32(const float* w, const float* bias, int Co, int C, int kh, int kw, int dg, int Cp, int ldw, float* wp,
+                            float* scale, float* shift, void* stream);
 /* sizeof the two descriptor structs as THIS library was compiled: an FFI binder (ctypes, cgo, JNI) asserts its own layout against
  * them, and the plan runtime rejects plan files whose descriptor blobs have another size */
 int cp_sizeof_conv_desc(void);

@@ -433,9 +433,11 @@ def test_dcn_v2_forward_deformable_groups(C, Co, dg, k, s, p, d, face):
 
 
 @pytest.mark.parametrize("face", ["python", "pybind"])
-def test_dcn_v2_forward_weight_cache_follows_parameter_updates(face):
-    """The ext faces cache the packed weights on (data_ptr, _version) of weight and bias: a second call reuses
-    them, an IN-PLACE update of either parameter (what an optimizer step or load_state_dict does) must be seen."""
+def test_dcn_v2_forward_follows_every_kind_of_parameter_update(face):
+    """The ext faces pack the weights with one device launch per call (round 5; rounds 3-4 cached the pack on (data_ptr, _version)).
+    ADVICE r4: an edit through `.data` -- what EMA / legacy loaders and the reference's own reset_parameters do (DCNv2/dcn_v2.py:44-52)
+    -- does not bump the version counter and was invisible to that cache; `_version` raises on inference tensors; a pack built on one
+    stream was read by others without an event.  All of these must simply work now, next to versioned in-place updates."""
     from oracle import dcn as odcn
     if face == "python":
         from centerpose_amd import dcn_v2_ext as ext
@@ -443,18 +445,52 @@ def test_dcn_v2_forward_weight_cache_follows_parameter_updates(face):
         from centerpose_amd import _ext as ext
     r = np.random.RandomState(3)
     x, off, m = r.randn(1, 32, 8, 8).astype(np.float32), r.randn(1, 18, 8, 8).astype(np.float32), r.rand(1, 9, 8, 8).astype(np.float32)
-    w = torch.from_numpy((r.randn(32, 32, 3, 3) * 0.2).astype(np.float32)).cuda()
-    b = torch.from_numpy(r.randn(32).astype(np.float32)).cuda()
+    w = torch.nn.Parameter(torch.from_numpy((r.randn(32, 32, 3, 3) * 0.2).astype(np.float32)).cuda())
+    b = torch.nn.Parameter(torch.from_numpy(r.randn(32).astype(np.float32)).cuda())
     t = [torch.from_numpy(a).cuda() for a in (x, off, m)]
     call = lambda: ext.dcn_v2_forward(t[0], w, b, t[1], t[2], 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    want = lambda: torch.from_numpy(odcn.dcn_v2_forward_c(x, w.detach().cpu().numpy(), b.detach().cpu().numpy(), off, m))
     o1, o2 = call(), call()
-    assert torch.equal(o1, o2)
-    _close(o1, torch.from_numpy(odcn.dcn_v2_forward_c(x, w.cpu().numpy(), b.cpu().numpy(), off, m)), 1e-4)
-    w.mul_(0.5)
-    b.add_(1.0)
+    assert torch.equal(o1, o2) and not o1.requires_grad
+    _close(o1, want(), 1e-4)
+    with torch.no_grad():                       # versioned in-place update (optimizer step, load_state_dict)
+        w.mul_(0.5)
+        b.add_(1.0)
     o3 = call()
-    _close(o3, torch.from_numpy(odcn.dcn_v2_forward_c(x, w.cpu().numpy(), b.cpu().numpy(), off, m)), 1e-4)
+    _close(o3, want(), 1e-4)
     assert not torch.equal(o3, o1)
+    v = w._version                              # `.data` edits: the version counter does NOT move
+    w.data.mul_(-2.0)
+    b.data.copy_(torch.from_numpy(r.randn(32).astype(np.float32)))
+    assert w._version == v
+    o4 = call()
+    _close(o4, want(), 1e-4)
+    assert not torch.equal(o4, o3)
+    with torch.inference_mode():                # inference tensors have no version counter at all
+        wi, bi = (w.detach() * 1.5).contiguous(), b.detach() + 0.25
+        oi = ext.dcn_v2_forward(t[0], wi, bi, t[1], t[2], 3, 3, 1, 1, 1, 1, 1, 1, 1)
+        ref = odcn.dcn_v2_forward_c(x, wi.cpu().numpy(), bi.cpu().numpy(), off, m)
+    _close(oi, torch.from_numpy(ref), 1e-4)
+    side = torch.cuda.Stream()                  # another stream: the pack is enqueued on the caller's stream, nothing is shared
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        o5 = call()
+    side.synchronize()
+    assert torch.equal(o5, o4)
+
+
+@pytest.mark.parametrize("face", ["python", "pybind"])
+def test_ext_exports_the_reference_modules_four_names(face):
+    """DCNv2/src/vision.cpp:6-9: dcn_v2_forward, dcn_v2_backward, dcn_v2_psroi_pooling_forward / _backward.  The last three raise
+    a clear RuntimeError (inference only / not on the hot path) instead of failing the attribute lookup."""
+    if face == "python":
+        from centerpose_amd import dcn_v2_ext as ext
+    else:
+        from centerpose_amd import _ext as ext
+    assert callable(ext.dcn_v2_forward)
+    for name in ("dcn_v2_backward", "dcn_v2_psroi_pooling_forward", "dcn_v2_psroi_pooling_backward"):
+        with pytest.raises(RuntimeError, match="hot path"):
+            getattr(ext, name)(*([None] * 15))
 
 
 @pytest.mark.parametrize("C,Co,dg,tile,S", [(64, 64, 2, 0, 1), (128, 128, 4, 64128, 1), (64, 64, 2, 0, 3), (96, 64, 3, 128064, 1)])

@@ -102,6 +102,43 @@ def test_allgather_eight_ranks_like_the_node():
     _run([16, 13], world=8)
 
 
+def _forced_world1_worker(q):
+    sys.path.insert(0, ROOT)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        os.environ.pop(k, None)
+    from centerpose_amd import dist as cpd
+    assert cpd.init_from_env("gloo") == (0, 1, 0) and not dist.is_initialized()          # default: no group at world 1
+    t = torch.arange(2 * 5 * 56, dtype=torch.float32).reshape(2, 5, 56)
+    assert cpd.gather_dets(t, force=True) is t                                            # no group: nothing to force
+    assert cpd.init_from_env("gloo", force=True) == (0, 1, 0) and dist.is_initialized() and dist.get_world_size() == 1
+    assert cpd.gather_dets(t) is t                                                        # pass-through unless forced
+    g = cpd.gather_dets(t, 2, force=True)
+    assert g is not t and torch.equal(g, t)
+    plain, forced = cpd.DetsGatherer(global_batch=2), cpd.DetsGatherer(global_batch=2, force=True)
+    assert not plain.active and forced.active and forced.side is None
+    plain.submit(t); forced.submit(t)
+    assert plain.collect() is t
+    c = forced.collect()
+    assert c is not t and torch.equal(c, t)
+    ok, _, msg = cpd.check_gathered(c, t, 2)
+    assert ok and msg.startswith("ok: 1 ranks"), msg
+    dist.barrier()
+    dist.destroy_process_group()
+    q.put("ok")
+
+
+def test_forced_world_of_one_runs_the_collective():
+    """`init_from_env(force=True)` + `DetsGatherer(force=True)`: a process group of ONE rank runs the same gather code as a
+    world of N (here over gloo; tests/test_dist_gpu.py does it over RCCL on the GPU box) instead of the world-1 pass-through."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_world1_worker, args=(q,))
+    p.start()
+    assert q.get(timeout=120) == "ok"
+    p.join(60)
+    assert p.exitcode == 0
+
+
 def test_shard_range_covers_batch():
     from centerpose_amd import dist as cpd
     for gb in (1, 7, 16, 128):

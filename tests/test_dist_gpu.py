@@ -72,6 +72,75 @@ dist.barrier(); dist.destroy_process_group()
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+def test_rccl_world_of_one_gatherer_on_side_stream(tmp_path):
+    """RCCL on the hardware a one-GPU lease has: a process group of ONE rank over nccl, `DetsGatherer(force=True)`:
+    the all_gather_into_tensor really runs as an RCCL kernel on the side stream while the next hipGraph replay of the engine runs
+    on the compute stream.  Proves communicator creation, the collective launch, the event ordering against graph replays and the
+    record_stream lifetimes -- everything of SURVEY 8e except the xGMI wire.  Bit-equal dets, sane exposed wait, clean shutdown."""
+    code = r"""
+import os, sys, time, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from centerpose_amd import dist as cpd, engine, synth
+rank, world, local = cpd.init_from_env("nccl", force=True)
+assert (rank, world) == (0, 1) and dist.get_backend() == "nccl" and dist.get_world_size() == 1
+torch.cuda.set_device(0)
+B = 2
+eng = engine.Engine("dla_34", synth.make_state_dict("dla_34"), B, 128, 128, device="cuda", use_graph=True, decode_k=100)
+imgs = [synth.make_images(B, 128, 128, seed=40 + i).cuda() for i in range(6)]
+want = []
+for x in imgs:                                   # reference pass: no gatherer at all
+    eng.input.copy_(x)
+    want.append(eng.process(eng.input)[1].clone())
+torch.cuda.synchronize()
+gat = cpd.DetsGatherer(global_batch=B, time_waits=True, force=True)
+assert gat.active and gat.side is not None and gat.time_waits
+got = []
+for x in imgs:                                   # pipelined: gather of step i runs beside the replay of step i + 1
+    eng.input.copy_(x)
+    _, dets = eng.process(eng.input)
+    if gat.pending:
+        got.append(gat.collect())
+    gat.submit(dets.clone())
+got.append(gat.collect())
+torch.cuda.synchronize()
+assert len(got) == len(want)
+for i, (g, w) in enumerate(zip(got, want)):
+    assert g.shape == (B, 100, 56) and torch.equal(g, w), "step %d: gathered dets differ" % i
+total, worst = gat.exposed_wait_ms()
+assert 0.0 <= worst <= total < 1000.0, (total, worst)
+ok, csum, msg = cpd.check_gathered(cpd.gather_dets(want[-1], B, force=True), want[-1], B)
+assert ok, msg
+t0 = time.time()
+dist.barrier(); dist.destroy_process_group()
+print("RCCL1_OK exposed_wait_ms total %.3f worst %.3f; %s; shutdown %.2f s" % (total, worst, msg, time.time() - t0))
+"""
+    script = tmp_path / "rccl_world1.py"
+    script.write_text(code)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script), ROOT], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0 and "RCCL1_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    print(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_force_gather_runs_rccl_on_one_gpu():
+    """`bench.py --gpus 1 --force-gather`: the N = 1 line with `backend: "nccl"`, `ranks: 1` and the gather diagnostics of the
+    N > 1 line (exposed wait of the side-stream collective, cross-rank checksum)."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "CP_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--steps", "4", "--warmup", "2",
+                        "--batch", "2", "--no-cpu-baseline", "--no-profile", "--gather-check"], capture_output=True, text=True, timeout=900,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert line["n_gpus"] == 1 and line["ranks"] == 1 and line["backend"] == "nccl" and line["value"] > 0
+    g = line["gather"]
+    assert g["check"].startswith("ok: 1 ranks") and "HIP events" in g["timed_with"]
+    assert 0.0 <= g["exposed_wait_ms_per_step"]["max_over_ranks"] < line["ms_per_step"]
+
+
 def test_bench_single_gpu_line_contract():
     """`python bench.py` as the driver runs it at N = 1 (short): ONE JSON line with the contract's keys, the metric / workload of
     BASELINE.json configs[2], dtype f32, a `roofline` object whose dominant-kernel time fits inside the step and whose fraction is

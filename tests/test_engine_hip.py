@@ -40,7 +40,7 @@ def test_forward_matches_reference_golden(arch, golden_dir):
 
 @pytest.mark.parametrize("arch,B,hw", [("dla_34", 3, (160, 96)), ("res_50", 2, (96, 160)), ("hrnet", 2, (64, 128)),
                                        ("mobilenetv3", 2, (96, 160)), ("shufflenetV2", 3, (160, 96)), ("resdcn_18", 3, (96, 160)),
-                                       ("resdcn_50", 2, (160, 96))])
+                                       ("resdcn_50", 2, (160, 96)), ("resdcn_34", 2, (96, 160)), ("resdcn_101", 2, (160, 96))])
 def test_forward_matches_oracle_ragged_shapes(arch, B, hw):
     """non-square inputs, batch > 1, hipGraph replay (twice: static buffers must be reusable)."""
     from centerpose_amd import engine, synth

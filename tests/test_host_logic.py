@@ -29,7 +29,7 @@ def test_synth_is_deterministic_and_complete():
 
 
 @pytest.mark.reference
-@pytest.mark.parametrize("arch", ["dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2", "resdcn_18", "resdcn_34", "resdcn_50"])
+@pytest.mark.parametrize("arch", ["dla_34", "res_50", "hrnet", "mobilenetv3", "shufflenetV2", "resdcn_18", "resdcn_34", "resdcn_50", "resdcn_101"])
 def test_spec_and_oracle_match_imported_reference(arch):
     """key names/shapes == the reference module's state_dict; torch oracle == reference forward."""
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))

@@ -40,13 +40,5 @@ sc, sh = ops.fold_bn(Co, None, b)
 out = torch.empty(B, H, W, Co, device="cuda")
 la = ops.dcn_v2_launch(xn, om, wp, sc, sh, out, cout=Co, om_sigmoid=False)
 print("in-plan kernel launch (NHWC, packed weights)      %.3f ms" % timeit(la.run))
-print("_ext.dcn_v2_forward (pybind, cached weights)      %.3f ms" % timeit(lambda: _ext.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)))
-print("dcn_v2_ext.dcn_v2_forward (python, cached weights) %.3f ms" % timeit(lambda: dcn_v2_ext.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)))
-
-
-def uncached():
-    w.add_(0.0)          # bumps the version: the packed weights are rebuilt
-    return _ext.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
-
-
-print("_ext.dcn_v2_forward, weights re-packed every call  %.3f ms" % timeit(uncached))
+print("_ext.dcn_v2_forward (pybind, packs per call)      %.3f ms" % timeit(lambda: _ext.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)))
+print("dcn_v2_ext.dcn_v2_forward (python, packs per call) %.3f ms" % timeit(lambda: dcn_v2_ext.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)))
