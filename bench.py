@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-MFMA_KERNELS = ("dcn_igemm_kernel", "conv3x3_wino", "head_wino24_kernel", "igemm_conv_kernel", "conv3x3_patch_kernel", "conv3x3_c16_kernel", "stem7x7_kernel", "stem7x7_c16_kernel")
+MFMA_KERNELS = ("dcn_igemm_kernel", "conv3x3_wino", "head_wino24_kernel", "igemm_conv_kernel", "igemm_bf16x3_kernel", "conv3x3_patch_kernel", "conv3x3_c16_kernel", "stem7x7_kernel", "stem7x7_c16_kernel")
 
 
 def parse_args():
@@ -197,31 +197,42 @@ def cpu_baseline(arch):
     top = max(cands)
     return {"value": top[0], "unit": "images/sec", "cores": top[1], "kind": "port",
             "sample": "%s 512x512 forward + sigmoid + decode, torch %s CPU fp32 oracle, warm (one untimed pass at the timed batch, then "
-                      ">= 3 timed passes); best layout: %s" % (arch, torch.__version__, top[2]),
+                      ">= 3 timed passes); best layout: %s.%s" % (arch, torch.__version__, top[2],
+                      " NOTE: the dla_34 host figure is bounded by the oracle's gather-based DCNv2 restatement (the reference has no "
+                      "CPU DCN at all), not by what the host can do; res_50_b1 / res_50_b8 (no DCN, oneDNN convolutions) are the "
+                      "credible host numbers." if arch.startswith("dla") else ""),
             "cpu_model": cpu_model_name(), "logical_cpus": ncpu, "physical_cores": phys,
             arch + "_b1": b1, arch + "_b8": b8, arch + "_multiprocess": layouts, "res_50_b1": r1, "res_50_b8": r8}
 
 
-def roofline(eng, arch, B):
+def roofline(eng, arch, B, wall_ms=None):
     """Per-kernel accounting of one step from in-sequence HIP-event timings (Engine.profile_in_sequence); kernels are the
-    template instantiations the launchers dispatched to (cp_last_kernel), named as rocprofv3 --kernel-trace prints them."""
+    template instantiations the launchers dispatched to (cp_last_kernel), named as rocprofv3 --kernel-trace prints them.
+    `wall_ms`: the timed step (two-stream graph replay) for `min_bound_frac.of_wall_step`."""
     recs = eng.profile_in_sequence(iters=10)
     fam = {}
+    min_bound_ms = 0.0
     for r in recs:
-        f = fam.setdefault(r["kernel"] or r["fn"], {"ms": 0.0, "flops": 0.0, "exe_flops": 0.0, "bytes": 0, "launches": 0})
+        f = fam.setdefault(r["kernel"] or r["fn"], {"ms": 0.0, "flops": 0.0, "exe_flops": 0.0, "bytes": 0, "launches": 0, "bound_ms": 0.0})
         f["ms"] += r["ms"]
         f["flops"] += r["flops"]
         # multiplies the matrix cores execute: F(2x2,3x3) 16 of the direct form's 36 per 2x2 tile, F(2x4,3x3) 24 of 72 per 2x4 tile
-        f["exe_flops"] += r["flops"] * {"wino": 16.0 / 36.0, "wino24": 24.0 / 72.0}.get(r["kind"], 1.0)
+        exe = r["flops"] * {"wino": 16.0 / 36.0, "wino24": 24.0 / 72.0}.get(r["kind"], 1.0)
+        f["exe_flops"] += exe
         f["bytes"] += r["bytes"]
         f["launches"] += 1
+        # SURVEY 8d's per-layer bound: the launch can finish no sooner than its executed MFMA work at the f32 matrix peak, nor
+        # sooner than its compulsory bytes (inputs + weights + outputs, each once) at the HBM peak
+        lb = max(exe / (PEAK_F32_MFMA_TFLOPS * 1e12), r["bytes"] / (PEAK_HBM_GBS * 1e9)) * 1e3
+        f["bound_ms"] += lb
+        min_bound_ms += lb
     all_ms = sum(f["ms"] for f in fam.values())
     # a kernel = one __global__ template; its tile instantiations (what rocprofv3 prints as separate rows) are summed: the DCNv2
     # kernel runs as <64,64,...> and, where 128 output channels still fill the CUs, as <64,128,...>
     grp = {}
     for k, f in fam.items():
-        g = grp.setdefault(k.split("<")[0], {"ms": 0.0, "flops": 0.0, "exe_flops": 0.0, "bytes": 0, "launches": 0, "inst": []})
-        for key in ("ms", "flops", "exe_flops", "bytes", "launches"):
+        g = grp.setdefault(k.split("<")[0], {"ms": 0.0, "flops": 0.0, "exe_flops": 0.0, "bytes": 0, "launches": 0, "bound_ms": 0.0, "inst": []})
+        for key in ("ms", "flops", "exe_flops", "bytes", "launches", "bound_ms"):
             g[key] += f[key]
         g["inst"].append(k)
     dom = max(grp, key=lambda k: grp[k]["ms"])
@@ -251,8 +262,15 @@ def roofline(eng, arch, B):
             # conv3x3_wino_kernel the largest by a few microseconds)
             "templates": {k: {"ms_per_step": round(g["ms"], 3), "share": round(g["ms"] / all_ms, 4), "launches": g["launches"],
                               "executed_tflops": round(tf(g["exe_flops"], g["ms"]), 2),
-                              "frac": round(tf(g["exe_flops"], g["ms"]) / PEAK_F32_MFMA_TFLOPS, 4)}
+                              "frac": round(tf(g["exe_flops"], g["ms"]) / PEAK_F32_MFMA_TFLOPS, 4),
+                              "min_bound_frac": round(g["bound_ms"] / g["ms"], 4),
+                              "compulsory_mb_per_launch": round(g["bytes"] / g["launches"] / 1e6, 2)}
                           for k, g in sorted(grp.items(), key=lambda kv: -kv[1]["ms"]) if g["exe_flops"] > 0},
+            # SURVEY 8d "report both the raw MFMA fraction and the min-bound fraction": per launch max(executed MFMA FLOPs at
+            # 157.3 TF, compulsory bytes at 8 TB/s), summed over the step, over the in-sequence time and over the timed wall step
+            "min_bound_frac": {"bound_ms_per_step": round(min_bound_ms, 3), "of_in_sequence": round(min_bound_ms / all_ms, 4),
+                               "of_wall_step": round(min_bound_ms / wall_ms, 4) if wall_ms else None,
+                               "definition": "sum over launches of max(executed MFMA flops / 157.3 TF, compulsory bytes / 8 TB/s) / time"},
             "all_mfma_kernels": {"ms_per_step": round(mm_ms, 3),
                                  "algorithmic_tflops": round(tf(sum(f["flops"] for f in mm), mm_ms), 2),
                                  "executed_tflops": round(tf(sum(f["exe_flops"] for f in mm), mm_ms), 2),
@@ -273,6 +291,14 @@ def roofline(eng, arch, B):
                 roof["traffic"] = int(sum((k["fetch_bytes_per_launch_corrected"] + k["write_bytes_per_launch"]) * n for k, n in ks) / sum(n for _, n in ks))
                 roof["traffic_unit"] = "bytes per launch (avg)"
                 roof["traffic_source"] = "profiles/%s (rocprofv3 --pmc, collected offline with this command)" % os.path.basename(src)
+            # per template: PMC bytes / compulsory bytes (1.0 = every byte moved once; > 1 = re-fetches that missed the L2 / MALL)
+            for name, g in grp.items():
+                ks = [(pmc["kernels"][i], fam[i]["launches"]) for i in g["inst"] if i in pmc["kernels"]]
+                if ks and name in roof["templates"] and g["bytes"] > 0:
+                    moved = sum((k["fetch_bytes_per_launch_corrected"] + k["write_bytes_per_launch"]) * n for k, n in ks)
+                    comp = sum(fam[i]["bytes"] for i in g["inst"] if i in pmc["kernels"])
+                    roof["templates"][name]["traffic_mb_per_launch"] = round(moved / sum(n for _, n in ks) / 1e6, 2)
+                    roof["templates"][name]["traffic_ratio"] = round(moved / comp, 3)
     except (OSError, KeyError, ValueError, IndexError):
         pass
     return roof
@@ -290,12 +316,18 @@ def other_configs(dev, steps=20, warmup=5):
     """BASELINE.json configs[1] (res_50 512x512 B=8) and the per-GPU shape of configs[4] (hrnet_w32 512x512 B=8) through the same
     engine / kernels, AFTER the timed region of the metric's own workload: `steps` graph replays each, timed like the main loop
     (host clock around synchronised replays), plus the in-sequence per-kernel accounting.  Not the metric -- driver-visible
-    evidence for the other configurations (VERDICT r3 #4)."""
+    evidence for the other configurations.  `res_50_b8_split_bf16`: res_50 B=8 once more with the
+    OPT-IN split-bf16 mode of the generic implicit GEMM (CP_SPLIT_BF16=1: three bf16 terms per fp32 operand, six bf16 MFMAs, fp32
+    accumulate); its kernel fractions are fp32-EQUIVALENT FLOPs over the f32 matrix peak and may exceed 1."""
     import torch
+    from centerpose_amd import ops
     out = {}
-    for arch, B in (("res_50", 8), ("hrnet", 8)):
+    for key, arch, B, split in (("res_50_b8", "res_50", 8, False), ("hrnet_b8", "hrnet", 8, False), ("res_50_b8_split_bf16", "res_50", 8, True)):
+        saved = ops.SPLIT_BF16
         try:
+            ops.SPLIT_BF16 = split
             eng = make_engine(arch, B, dev)
+            ops.SPLIT_BF16 = saved
             x = eng.input
             for _ in range(warmup):
                 eng.process(x)
@@ -305,17 +337,22 @@ def other_configs(dev, steps=20, warmup=5):
                 eng.process(x)
             torch.cuda.synchronize()
             el = time.perf_counter() - t0
-            r = roofline(eng, arch, B)
-            out["%s_b%d" % (arch, B)] = {
+            r = roofline(eng, arch, B, wall_ms=el / steps * 1e3)
+            out[key] = {
                 "images_per_sec": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
                 "graph_capture": eng.capture_mode, "end_to_end_tflops": round(eng.flops_per_image * B * steps / el / 1e12, 2),
                 "all_mfma_executed_frac": r["all_mfma_kernels"]["executed_frac"],
+                "min_bound_frac": r["min_bound_frac"],
                 "dominant_kernel": r["kernel"], "dominant_frac": r["frac"], "dominant_time_share": r["time_share"],
                 "templates": r["templates"]}
+            if split:
+                out[key]["mode"] = "CP_SPLIT_BF16=1 (opt-in, fp32-equivalent 3-term bf16 split on v_mfma_f32_32x32x16_bf16; NOT the metric's arithmetic path)"
             del eng
             torch.cuda.empty_cache()
         except Exception as e:            # evidence, not the metric: a failure here must not take the bench line down
-            out["%s_b%d" % (arch, B)] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        finally:
+            ops.SPLIT_BF16 = saved
     return out
 
 
@@ -424,7 +461,18 @@ def main():
                 "end_to_end_tflops": round(eng.flops_per_image * value / world / 1e12, 2),
                 "activation_mb": round(eng.activation_bytes / 1e6, 1)}
         if not args.no_profile:
-            line["roofline"] = roofline(eng, args.arch, B)
+            line["roofline"] = roofline(eng, args.arch, B, wall_ms=ms_step)
+            # DVFS (MI355X_MICROARCH.md: short bursts clock higher): the same step over >= 1000 replays AFTER the timed region
+            n_sus = max(1000, args.steps)
+            torch.cuda.synchronize()
+            ts = time.perf_counter()
+            for _ in range(n_sus):
+                eng.process(eng.input)
+            torch.cuda.synchronize()
+            sus = time.perf_counter() - ts
+            line["sustained"] = {"replays": n_sus, "seconds": round(sus, 3), "images_per_sec": round(B * n_sus / sus, 1),
+                                 "ms_per_step": round(sus / n_sus * 1e3, 3),
+                                 "note": "graph replays back to back after the timed region, one host sync at the end (no gather, no clone)"}
             # ---- decode alone (latency-bound; reported as us/batch next to its HBM GB/s) ------------------
             hm, wh, hps, reg, hm_hp, hp_offset = eng.outputs
             for _ in range(3):

@@ -210,15 +210,23 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
     } else ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc, ooys, ooxs);
 }
 
+// `occ` (tile code digit 8, tuning / experiments): at most that many blocks per CU, enforced by asking for 160 KiB / occ of dynamic
+// LDS -- a launch whose blocks all fit on the chip at once runs its prologue, MFMA and epilogue phases in lock-step; fewer resident
+// blocks stagger them (tools/igemm_ab.py)
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, bool STEM>
-static int launch_conv(const ConvArgs& a, hipStream_t s)
+static int launch_conv(const ConvArgs& a, hipStream_t s, int occ = 0)
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
     auto kern = igemm_conv_kernel<BM, BN, WAVES_M, WAVES_N, MF, STEM>;
     if (a.ldw % BN != 0) { cp_set_error("conv2d: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
-    const int smem = a.outNCHW ? T::SMEM : T::NHWC_BYTES;
+    int smem = a.outNCHW ? T::SMEM : T::NHWC_BYTES;
     static CpLdsGuard guard;
-    constexpr int smem_max = T::SMEM > T::NHWC_BYTES ? T::SMEM : T::NHWC_BYTES;
+    int smem_max = T::SMEM > T::NHWC_BYTES ? T::SMEM : T::NHWC_BYTES;
+    if (occ > 0) {
+        const int want = (160 * 1024 / occ) & ~255;
+        if (want > smem) smem = want;
+        if (want > smem_max) smem_max = want;
+    }
     if (smem > 64 * 1024) {
         const hipError_t e = guard.ensure((const void*)kern, smem_max);
         if (e != hipSuccess) { cp_set_error("conv2d: cannot reserve %d B LDS: %s", smem_max, hipGetErrorString(e)); return 2; }
@@ -304,6 +312,14 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
     hipStream_t s = (hipStream_t)stream;
 
     int tile = d->tile;
+    if (tile >= 3000000 && tile < 4000000) {                                             // opt-in split-bf16 kernel (conv_igemm_bf16x3.hip): w = pre-split weights
+        CP_CHECK_ARG(!d->inNCHW, "conv2d: the split-bf16 kernel takes NHWC sources");
+        CP_CHECK_ARG(a.nsub == 1 || (a.nsub == 4 && d->osy == 2 && d->osx == 2 && d->ooy == 0 && d->oox == 0 && d->kh == 2 && d->kw == 2),
+                     "conv2d: nsub=4 is the fused k4/s2/p1 deconvolution (2x2 taps, output stride 2)");
+        if (int rc = cp_launch_conv_bf16x3(a, tile, s)) return rc;
+        CP_CHECK_LAUNCH("igemm_bf16x3_kernel");
+        return 0;
+    }
     if (a.nsub > 1) {
         CP_CHECK_ARG(a.nsub == 4 && !d->inNCHW && d->osy == 2 && d->osx == 2 && d->ooy == 0 && d->oox == 0 && d->kh == 2 && d->kw == 2,
                      "conv2d: nsub=4 is the fused k4/s2/p1 deconvolution (2x2 taps, output stride 2)");
@@ -346,6 +362,8 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
         }
     }
     int rc = 0;
+    const int occ = tile / 10000000;           // 0 = no limit
+    tile %= 10000000;
     if (d->inNCHW) {
         switch (tile) {
             case 256016: rc = launch_conv<256, 16, 4, 1, 16, true>(a, s); break;
@@ -357,9 +375,9 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
         switch (tile) {
             case 256016: rc = launch_conv<256, 16, 4, 1, 16, false>(a, s); break;
             case 128032: rc = launch_conv<128, 32, 4, 1, 32, false>(a, s); break;
-            case 128064: rc = launch_conv<128, 64, 2, 2, 32, false>(a, s); break;
-            case 64064: rc = launch_conv<64, 64, 2, 2, 32, false>(a, s); break;
-            case 128128: rc = launch_conv<128, 128, 2, 2, 32, false>(a, s); break;
+            case 128064: rc = launch_conv<128, 64, 2, 2, 32, false>(a, s, occ); break;
+            case 64064: rc = launch_conv<64, 64, 2, 2, 32, false>(a, s, occ); break;
+            case 128128: rc = launch_conv<128, 128, 2, 2, 32, false>(a, s, occ); break;
             default: CP_CHECK_ARG(false, "conv2d: unknown tile %d", tile);
         }
     }

@@ -56,8 +56,9 @@ struct ConvArgs {
     int omMaskOff;            // first mask channel (2*kh*kw)
     int omSigmoid;            // 1: mask channel holds logits (apply sigmoid), 0: mask given directly
     int dily, dilx;           // dilation (DCNv2 drop-in only; plain convs are dilation 1)
-    int ksplit;               // DCNv2 only: > 1 = split-K over the taps: block (tile, split s) accumulates taps [s*T/S, (s+1)*T/S) and
-                              // stores the RAW partial sums to out + s*M*outLd (cp_splitk_reduce_f32 sums them in a fixed order)
+    int ksplit;               // > 1 = split-K: block (tile, split s) accumulates its share of the reduction (DCNv2: taps [s*T/S, (s+1)*T/S); generic
+                              // kernels: k-steps [s*nk/S, (s+1)*nk/S)) and stores the RAW partial sums to out + s*M*outLd
+                              // (cp_splitk_reduce_f32 sums them in a fixed order)
     int dg;                   // DCNv2 only: deformable groups (>= 1)
     int nsub;                 // 1, or 4: the four sub-pixel 2x2 convs of a k4/s2/p1 ConvTranspose2d in ONE launch (generic kernel only):
                               // sub g = py*2+px uses weights w + g*ldw*K, pad (py0 - py, px0 - px) and output phase (ooy + py, oox + px)
@@ -78,6 +79,9 @@ int cp_launch_head3x3_1x1_w24(const ConvArgs& a, const float* w2, const float* b
 int cp_launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s);
 // conv3x3_wino.hip: [3x3 + bias + ReLU] + 1x1 (n2 <= 2 outputs, NCHW) of a head branch in one launch; -1 = shape not eligible
 int cp_launch_head3x3_1x1(const ConvArgs& a, const float* w2, const float* b2, float* out2, int n2, int ld2, int act2, hipStream_t s);
+
+// conv_igemm_bf16x3.hip: the generic implicit GEMM as an fp32-equivalent 3-term split on the bf16 matrix pipe (opt-in; a.w = pre-split weights)
+int cp_launch_conv_bf16x3(const ConvArgs& a, int tile, hipStream_t s);
 
 // 16-byte load through an explicit GLOBAL address-space pointer.  A generic (flat) load also increments
 // lgkmcnt, so every `s_waitcnt lgkmcnt` guarding an LDS fragment read would wait for the prefetch as well.

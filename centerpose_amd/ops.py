@@ -179,6 +179,38 @@ def _ld(t):
     return t.stride(2)
 
 
+# ---- opt-in split-bf16 mode of the generic implicit GEMM (conv_igemm_bf16x3.hip) -------------------------------
+# CP_SPLIT_BF16=1 (or ops.SPLIT_BF16 = True before a plan is compiled): generic NHWC launches whose padded output channels are a
+# multiple of 64 run as an fp32-EQUIVALENT 3-term bf16 split on the bf16 matrix pipe (six bf16 MFMAs per fp32 product tile, fp32
+# accumulate, dropped terms <= 2^-24 relative).  Never the default; the timed configuration and `dtype: "f32"` stay on the f32 MFMA.
+SPLIT_BF16 = os.environ.get("CP_SPLIT_BF16", "0") == "1"
+SPLIT_BF16_TILE = {128: 3128128, 64: 3128064}          # cp_conv_desc.tile codes by N tile
+
+
+def split_bf16_weight(wp, ldw):
+    """packed fp32 weights [nsub * ldw, K] (device) -> pre-split bf16 [nsub][K/16][ldw][3 terms][16 k] (cp_split_bf16_weights_f32),
+    carried as a float32 tensor of the same bytes so that plans serialise it like any other constant."""
+    L = _lib.lib()
+    rows, K = wp.shape
+    assert rows % ldw == 0 and K % 16 == 0 and wp.is_contiguous()
+    L.cp_split_bf16_weight_floats.restype = ctypes.c_size_t
+    wb = torch.empty((L.cp_split_bf16_weight_floats(rows, K),), dtype=torch.float32, device=wp.device)
+    _lib.check(L.cp_split_bf16_weights_f32(_lib.ptr(wp), rows, ldw, K, _lib.ptr(wb), _lib.stream()), "cp_split_bf16_weights_f32")
+    return wb
+
+
+def split_bf16_tile(M, ldw, nsub=1, ksplit=1):
+    """N tile of the split-bf16 kernel for a launch with M output pixels per sub-convolution: 128 when the 128 x 128 tiling still gives
+    every CU a block, else 64; None when ldw is not a multiple of 64 (the launch stays on the f32 kernel)."""
+    if ldw % 64:
+        return None
+    blocks = ((M + 127) // 128) * max(1, nsub) * max(1, ksplit)
+    forced = os.environ.get("CP_SPLIT_BF16_TILE")
+    if forced:
+        return int(forced) if ldw % int(forced) == 0 else 64
+    return 128 if ldw % 128 == 0 and blocks * (ldw // 128) >= 256 else 64
+
+
 def conv2d(srcs, wp, scale, shift, out, **kw):
     """Enqueue `conv2d_launch(...)` now (eager use: tests, tools)."""
     conv2d_launch(srcs, wp, scale, shift, out, **kw).run()
@@ -186,7 +218,7 @@ def conv2d(srcs, wp, scale, shift, out, **kw):
 
 
 def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout, act=ACT_NONE, res=None, out_nchw=False,
-                  in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0, wino=None, nsub=1, ksplit=0):
+                  in_nchw=False, Ho=None, Wo=None, pad_yx=None, out_scatter=None, tile=0, wino=None, nsub=1, ksplit=0, split_bf16=None):
     """Fused conv: out = act((sum_src conv(src)) * scale + shift [+ res]).
 
     nsub = 4: the four sub-pixel 2x2 convs of a dense ConvTranspose2d(k4,s2,p1) in one launch; wp = [4*ldw, K] (sub g = py*2+px),
@@ -195,6 +227,9 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
     F(2x2,3x3) kernel (cp_conv3x3_winograd_f32); `tile` then selects 32 (1) / 64 (2) channels per block.
     ksplit = S > 1 (Winograd only): split over the input channels; `out` is the workspace [S, B*H*W, ld] of raw partial outputs
     (scale = ones, shift = zeros, no act / residual) and `splitk_reduce_launch` finishes the layer.
+
+    split_bf16: None = the module switch `SPLIT_BF16` (CP_SPLIT_BF16=1), True / False = this launch; taken only by generic launches
+    (tile = 0, NHWC sources, no Winograd weights) with ldw % 64 == 0: the weights are split here (plan time) and the launch carries them.
 
     srcs: list of NHWC tensors (concatenated along C) or one NCHW tensor when in_nchw.
     out : NHWC [B,OH,OW,>=cout] (or NCHW [B,cout,OH,OW] when out_nchw).
@@ -238,6 +273,12 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
     if wino is not None:
         assert len(srcs) == 1 and not in_nchw
         return Launch("cp_conv3x3_winograd_f32", d, [srcs[0], wino, scale, shift, res, out])
+    if (SPLIT_BF16 if split_bf16 is None else split_bf16) and tile == 0 and not in_nchw:
+        bn = split_bf16_tile(B * Ho * Wo, d.ldw, nsub, ksplit)
+        c16 = kh == 3 and kw == 3 and len(srcs) == 1 and srcs[0].shape[3] == 16 and cout <= 32      # stays on conv3x3_c16_kernel
+        if bn is not None and not c16 and all(s.data_ptr() % 16 == 0 for s in srcs):
+            d.tile = SPLIT_BF16_TILE[bn]
+            wp = split_bf16_weight(wp, d.ldw)
     return Launch("cp_conv2d_f32", d, list(srcs) + [None] * (4 - len(srcs)) + [wp, scale, shift, res, out])
 
 

@@ -56,6 +56,109 @@ def test_conv_bn_relu_residual(cin, cout, k, s, p, hw, tile):
     _close(out.permute(0, 3, 1, 2), ref)
 
 
+@pytest.mark.parametrize("cin,cout,k,s,p,hw,bn_tile", [
+    (32, 64, 3, 1, 1, (20, 28), 64), (64, 128, 1, 1, 0, (9, 9), 128), (64, 128, 1, 1, 0, (9, 9), 64), (256, 512, 3, 2, 1, (8, 8), 128),
+    (48, 128, 3, 1, 1, (24, 24), 128), (128, 64, 1, 1, 0, (33, 17), 64), (1024, 256, 1, 1, 0, (7, 5), 128), (16, 64, 3, 2, 1, (33, 17), 64),
+])
+def test_conv_split_bf16_matches_f32_kernel_tolerance(cin, cout, k, s, p, hw, bn_tile):
+    """The OPT-IN split-bf16 kernel (conv_igemm_bf16x3.hip: three bf16 terms per fp32 operand, six bf16 MFMAs, fp32 accumulate) on the
+    cases of test_conv_bn_relu_residual, at the SAME tolerance as the f32-MFMA kernel, and within 2x of that kernel's own error
+    against an fp64 reference (ragged M / edge tiles, stride 2, residual, 1x1 and 3x3, both N tiles)."""
+    from centerpose_amd import _lib, ops
+    g = torch.Generator().manual_seed(cin * 131 + cout)
+    B, (H, W) = 3, hw
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    bn = _rand_bn(g, cout)
+    res = None
+    ref64 = F.conv2d(x.double(), w.double(), None, s, p)
+    gm, b, m, v = (t.double() for t in bn)
+    ref64 = (ref64 - m[None, :, None, None]) / torch.sqrt(v[None, :, None, None] + 1e-5) * gm[None, :, None, None] + b[None, :, None, None]
+    res = torch.randn(ref64.shape, generator=g)
+    ref64 = F.relu(ref64 + res.double())
+    wp = ops.pack_conv_weight(w.cuda())
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    Ho, Wo = ref64.shape[2:]
+    outs = {}
+    for mode in ("f32", "bf16x3"):
+        out = torch.full((B, Ho, Wo, cout), float("nan"), device="cuda")
+        if mode == "f32":
+            ops.conv2d([_nhwc(x)], wp, sc, sh, out, kh=k, kw=k, stride=s, pad=p, cout=cout, act=ops.ACT_RELU, res=_nhwc(res), tile=64064)
+        else:
+            import os
+            os.environ["CP_SPLIT_BF16_TILE"] = str(bn_tile)
+            try:
+                ops.conv2d([_nhwc(x)], wp, sc, sh, out, kh=k, kw=k, stride=s, pad=p, cout=cout, act=ops.ACT_RELU, res=_nhwc(res), split_bf16=True)
+            finally:
+                del os.environ["CP_SPLIT_BF16_TILE"]
+            assert _lib.lib().cp_last_kernel().decode() == "igemm_bf16x3_kernel<128, %d>" % bn_tile
+        outs[mode] = out.permute(0, 3, 1, 2)
+        _close(outs[mode], ref64.float())
+    e32 = (outs["f32"].cpu().double() - ref64).abs().max().item()
+    e16 = (outs["bf16x3"].cpu().double() - ref64).abs().max().item()
+    print("%d->%d k%d s%d %s: max err vs fp64  f32 MFMA %.2e   split-bf16 %.2e" % (cin, cout, k, s, hw, e32, e16))
+    assert e16 <= 2.0 * e32 + 1e-7
+
+
+def test_conv_split_bf16_concat_deconv_splitk_nchw():
+    """The other producers / epilogues of the generic kernel through the split-bf16 kernel: concatenated sources with channel views
+    (DLA Root), the fused sub-pixel deconvolution (nsub = 4), split-K + fixed-order reduction, and the NCHW head output."""
+    from centerpose_amd import _lib, ops
+    g = torch.Generator().manual_seed(7)
+    B, H, W = 2, 10, 14
+    xs = [torch.randn(B, c, H, W, generator=g) for c in (64, 32, 16, 48)]
+    w = torch.randn(128, 160, 1, 1, generator=g) * 0.1
+    bias = torch.randn(128, generator=g)
+    ref = F.relu(F.conv2d(torch.cat(xs, 1), w, bias))
+    wide = torch.randn(B, H, W, 96, generator=g).cuda()
+    wide[..., 32:64] = _nhwc(xs[1])
+    srcs = [_nhwc(xs[0]), wide[..., 32:64], _nhwc(xs[2]), _nhwc(xs[3])]
+    sc, sh = ops.fold_bn(128, None, bias.cuda())
+    out = torch.empty(B, H, W, 128, device="cuda")
+    ops.conv2d(srcs, ops.pack_conv_weight(w.cuda()), sc, sh, out, kh=1, kw=1, cout=128, act=ops.ACT_RELU, split_bf16=True)
+    assert _lib.lib().cp_last_kernel().decode().startswith("igemm_bf16x3_kernel")
+    _close(out.permute(0, 3, 1, 2), ref)
+    # fused sub-pixel deconvolution
+    C, Co, H, W = 32, 64, 9, 11
+    x = torch.randn(B, C, H, W, generator=g)
+    wd = torch.randn(C, Co, 4, 4, generator=g) * 0.1
+    bn = _rand_bn(g, Co)
+    ref = F.relu(_ref_bn(F.conv_transpose2d(x, wd, None, 2, 1), bn))
+    sc, sh = ops.fold_bn(Co, tuple(t.cuda() for t in bn))
+    out4 = torch.full((B, 2 * H, 2 * W, Co), float("nan"), device="cuda")
+    wp4 = torch.cat([ops.pack_deconv4_subpixel(wd.cuda(), py_, px_) for py_ in range(2) for px_ in range(2)], 0).contiguous()
+    ops.conv2d([_nhwc(x)], wp4, sc, sh, out4, kh=2, kw=2, stride=1, pad=0, pad_yx=(1, 1), cout=Co, act=ops.ACT_RELU, Ho=H, Wo=W,
+               out_scatter=(2, 2, 0, 0), nsub=4, split_bf16=True)
+    assert _lib.lib().cp_last_kernel().decode().startswith("igemm_bf16x3_kernel")
+    _close(out4.permute(0, 3, 1, 2), ref)
+    # split-K (raw partial sums) + reduction
+    cin, cout, S = 512, 128, 3
+    x = torch.randn(B, cin, 6, 7, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    bn = _rand_bn(g, cout)
+    ref = F.relu(_ref_bn(F.conv2d(x, w, None, 2, 1), bn))
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    wp = ops.pack_conv_weight(w.cuda())
+    M, ldw = B * ref.shape[2] * ref.shape[3], wp.shape[0]
+    ws = torch.full((S, M, ldw), float("nan"), device="cuda")
+    ops.conv2d([_nhwc(x)], wp, torch.ones(ldw, device="cuda"), torch.zeros(ldw, device="cuda"), ws, kh=3, kw=3, stride=2, pad=1, cout=ldw,
+               ksplit=S, split_bf16=True)
+    assert _lib.lib().cp_last_kernel().decode().startswith("igemm_bf16x3_kernel")
+    out = torch.empty(B, ref.shape[2], ref.shape[3], cout, device="cuda")
+    ops.splitk_reduce_launch(ws, sc, sh, out, cout=cout, act=ops.ACT_RELU).run()
+    _close(out.permute(0, 3, 1, 2), ref)
+    # NCHW output + sigmoid (ldw = 64 for 34 outputs)
+    x = torch.randn(2, 64, 12, 20, generator=g)
+    w = torch.randn(34, 64, 1, 1, generator=g) * 0.2
+    b = torch.randn(34, generator=g)
+    ref = torch.sigmoid(F.conv2d(x, w, b))
+    sc, sh = ops.fold_bn(34, None, b.cuda())
+    out = torch.empty(2, 34, 12, 20, device="cuda")
+    ops.conv2d([_nhwc(x)], ops.pack_conv_weight(w.cuda()), sc, sh, out, kh=1, kw=1, cout=34, act=2, out_nchw=True, split_bf16=True)
+    assert _lib.lib().cp_last_kernel().decode().startswith("igemm_bf16x3_kernel")
+    _close(out, ref, 1e-5)
+
+
 def test_conv_concat_sources_and_channel_views():
     """Root: cat -> 1x1 conv (pose_dla_dcn.py:155-163) without materialising the cat; sources may be
     channel slices of wider tensors (pixel stride > C)."""

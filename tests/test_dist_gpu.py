@@ -170,3 +170,15 @@ def test_bench_single_gpu_line_contract():
         oc = line["other_configs"][k]
         assert "error" not in oc, oc
         assert oc["images_per_sec"] > 0 and oc["graph_capture"] == "2-stream" and 0.2 < oc["all_mfma_executed_frac"] < 1.0
+        assert 0.1 < oc["min_bound_frac"]["of_in_sequence"] <= 1.0
+    # round 5: what a reader had to recompute -- the min-bound fraction, per-template traffic ratios from
+    # the committed PMC passes, a sustained figure over >= 1000 replays -- and (#1) the opt-in split-bf16 evidence run
+    mb = roof["min_bound_frac"]
+    assert 0.3 < mb["of_in_sequence"] <= 1.0 and 0.3 < mb["of_wall_step"] <= 1.05 and mb["bound_ms_per_step"] < line["ms_per_step"]
+    assert all(0.0 < t["min_bound_frac"] <= 1.05 for t in roof["templates"].values())
+    assert any("traffic_ratio" in t for t in roof["templates"].values())
+    sus = line["sustained"]
+    assert sus["replays"] >= 1000 and 0.8 * line["value"] < sus["images_per_sec"] < 1.2 * line["value"]
+    sb = line["other_configs"]["res_50_b8_split_bf16"]
+    assert "error" not in sb, sb
+    assert "igemm_bf16x3_kernel" in sb["templates"] and "CP_SPLIT_BF16=1" in sb["mode"] and sb["images_per_sec"] > 0

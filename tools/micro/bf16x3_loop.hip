@@ -1,0 +1,207 @@
+// Micro-benchmark (stage A): ceiling of an fp32-EQUIVALENT GEMM inner loop on the bf16 matrix pipe of gfx950.
+// Every fp32 operand is three bf16 terms (x = x1 + x2 + x3 exactly, 8+8+8 significand bits, round-to-nearest at each level); the
+// six significant cross products x1y1, x1y2, x2y1, x1y3, x2y2, x3y1 go to v_mfma_f32_32x32x16_bf16 with fp32 accumulate
+// (dropped terms <= 2^-24 relative).  Ceiling 2516 / 6 = 419 TF fp32-equivalent against 157.3 TF on the f32 MFMA.
+// One iteration = one k-step (16) of a wave's 64 x 64 output tile: 4 tiles x 6 MFMAs.
+//   MODE 0  register-fed (pipe ceiling)            MODE 1  + 12 ds_read_b128 (3 terms x (2 A + 2 B) fragments)
+//   MODE 2  + split of 8 fresh fp32 activations per thread (v_cvt_pk_bf16_f32 / v_pk_add_f32) + 6 ds_write_b128 + barrier
+//   MODE 3  + the k-step's global loads (2 float4 A + 3 uint4 pre-split B per thread, L2-resident)
+// The last line is the f32 MFMA loop of mfma_peak.hip (LDS-fed, same process) = "the fp32 loop" of the kill criterion.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ unsigned cvt2(float a, float b)
+{
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ void split2(float x0, float x1, unsigned& p1, unsigned& p2, unsigned& p3)
+{
+    p1 = cvt2(x0, x1);
+    const float r0 = x0 - __builtin_bit_cast(float, p1 << 16), r1 = x1 - __builtin_bit_cast(float, p1 & 0xffff0000u);
+    p2 = cvt2(r0, r1);
+    p3 = cvt2(r0 - __builtin_bit_cast(float, p2 << 16), r1 - __builtin_bit_cast(float, p2 & 0xffff0000u));
+}
+__device__ __forceinline__ f32x16 mm(v4u a, v4u b, f32x16 c)
+{
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+#define LDR 28      // LDS row stride in dwords: 3 terms x 16 bf16 + 16 B pad (conflict-free ds_read_b128)
+
+template <int MODE, int BPC>
+__global__ __launch_bounds__(256, BPC) void k(float* out, const float* __restrict__ ga, const unsigned* __restrict__ gb, int iters)
+{
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * 256 * LDR];      // [buf][A 128 rows | B 128 rows][LDR]
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 2 * 256 * LDR; i += 256) lds[i] = 0x3f803f80u + (i & 7);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int g = lane >> 5, il = lane & 31, wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+    v4u af[2][3], bf[2][3];
+    for (int i = 0; i < 2; ++i) for (int t = 0; t < 3; ++t) { af[i][t] = (v4u){0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; bf[i][t] = af[i][t]; }
+    const float* pa = ga + (size_t)(blockIdx.x & 63) * 128 * 1024 + (tid >> 1) * 1024 + (tid & 1) * 8;
+    const unsigned* pb = gb + tid * 4;
+    v4f a0 = {1.f, 1.5f, 0.3f, 0.7f}, a1 = {0.1f, 0.9f, 2.3f, 0.01f};
+    v4u b0 = {}, b1 = {}, b2 = {};
+    int cur = 0;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        const unsigned* As = lds + cur * 256 * LDR;
+        const unsigned* Bs = As + 128 * LDR;
+        if (MODE >= 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    af[i][t] = *reinterpret_cast<const v4u*>(As + (wm0 + i * 32 + il) * LDR + t * 8 + g * 4);
+                    bf[i][t] = *reinterpret_cast<const v4u*>(Bs + (wn0 + i * 32 + il) * LDR + t * 8 + g * 4);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (MODE >= 3 && i == 1 && j == 0) {          // next k-step's loads from inside the MFMA block
+                    const int ko = (it & 63) * 16;
+                    a0 = *(const __attribute__((address_space(1))) v4f*)(pa + ko);
+                    a1 = *(const __attribute__((address_space(1))) v4f*)(pa + ko + 4);
+                    b0 = *(const __attribute__((address_space(1))) v4u*)(pb + (it & 63) * 3072);
+                    b1 = *(const __attribute__((address_space(1))) v4u*)(pb + (it & 63) * 3072 + 1024);
+                    b2 = *(const __attribute__((address_space(1))) v4u*)(pb + (it & 63) * 3072 + 2048);
+                }
+                acc[i][j] = mm(af[i][2], bf[j][0], acc[i][j]);
+                acc[i][j] = mm(af[i][1], bf[j][1], acc[i][j]);
+                acc[i][j] = mm(af[i][0], bf[j][2], acc[i][j]);
+                acc[i][j] = mm(af[i][1], bf[j][0], acc[i][j]);
+                acc[i][j] = mm(af[i][0], bf[j][1], acc[i][j]);
+                acc[i][j] = mm(af[i][0], bf[j][0], acc[i][j]);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (MODE >= 2) {
+            unsigned* An = lds + (cur ^ 1) * 256 * LDR;
+            unsigned* Bn = An + 128 * LDR;
+            if (MODE == 2) { a0 += 0.25f; a1 *= 1.0001f; b0 += 1u; }
+            v4u t1, t2, t3, u1, u2, u3;
+            unsigned q1[4], q2[4], q3[4];
+            split2(a0.x, a0.y, q1[0], q2[0], q3[0]); split2(a0.z, a0.w, q1[1], q2[1], q3[1]);
+            split2(a1.x, a1.y, q1[2], q2[2], q3[2]); split2(a1.z, a1.w, q1[3], q2[3], q3[3]);
+            t1 = (v4u){q1[0], q1[1], q1[2], q1[3]}; t2 = (v4u){q2[0], q2[1], q2[2], q2[3]}; t3 = (v4u){q3[0], q3[1], q3[2], q3[3]};
+            unsigned* ar = An + (tid >> 1) * LDR + (tid & 1) * 4;
+            *reinterpret_cast<v4u*>(ar) = t1; *reinterpret_cast<v4u*>(ar + 8) = t2; *reinterpret_cast<v4u*>(ar + 16) = t3;
+            u1 = b0; u2 = b1; u3 = b2;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int idx = tid + s * 256;
+                *reinterpret_cast<v4u*>(Bn + (idx / 6) * LDR + (idx % 6) * 4) = s == 0 ? u1 : s == 1 ? u2 : u3;
+            }
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s + a0.x + (float)b0.x;
+}
+
+// the f32 MFMA loop (as tools/micro/mfma_peak.hip MODE 1, 2 x 2 tiles per wave: 4 A/B b128 reads per 16 MFMAs of 32x32x2)
+template <int BPC>
+__global__ __launch_bounds__(256, BPC) void kf32(float* out, int iters)
+{
+    __shared__ __attribute__((aligned(16))) float lds[2 * 256 * 20];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 2 * 256 * 20; i += 256) lds[i] = 0.001f * (i & 63);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int g = lane >> 5, il = lane & 31, wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        const float* As = lds + (it & 1) * 256 * 20;
+        const float* Bs = As + 128 * 20;
+        v4f af[2][2], bf[2][2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[h][i] = *reinterpret_cast<const v4f*>(As + (wm0 + i * 32 + il) * 20 + h * 8 + g * 4);
+                bf[h][i] = *reinterpret_cast<const v4f*>(Bs + (wn0 + i * 32 + il) * 20 + h * 8 + g * 4);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[h][i][e], bf[h][j][e], acc[i][j], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+static float* g_out; static float* g_a; static unsigned* g_b;
+
+template <int MODE, int BPC> double run(const char* name)
+{
+    const int iters = 4000, grid = 256 * BPC;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    k<MODE, BPC><<<grid, 256>>>(g_out, g_a, g_b, 50);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        k<MODE, BPC><<<grid, 256>>>(g_out, g_a, g_b, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double eq = (double)grid * 4 * iters * 4 * 2.0 * 32 * 32 * 16;      // fp32-equivalent flops
+    const double tf = eq / best / 1e9;
+    printf("%-66s blocks/CU=%d  %8.3f ms  %7.1f TF fp32-equivalent  (%6.1f TF bf16 MFMA issued)\n", name, BPC, best, tf, tf * 6);
+    return tf;
+}
+template <int BPC> double runf32()
+{
+    const int iters = 4000, grid = 256 * BPC;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kf32<BPC><<<grid, 256>>>(g_out, 50);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        kf32<BPC><<<grid, 256>>>(g_out, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double tf = (double)grid * 4 * iters * 4 * 2.0 * 32 * 32 * 16 / best / 1e9;
+    printf("%-66s blocks/CU=%d  %8.3f ms  %7.1f TF fp32\n", "f32 MFMA loop (32x32x2), LDS-fed 2x2 tiles, no staging", BPC, best, tf);
+    return tf;
+}
+int main()
+{
+    hipMalloc(&g_out, 256 * 4 * 256 * sizeof(float));
+    hipMalloc(&g_a, 64 * 128 * 1024 * sizeof(float)); hipMemset(g_a, 0, 64 * 128 * 1024 * sizeof(float));
+    hipMalloc(&g_b, 64 * 3072 * sizeof(unsigned)); hipMemset(g_b, 0, 64 * 3072 * sizeof(unsigned));
+    run<0, 1>("bf16x3 register-fed (24 MFMA / k-step)");
+    run<0, 2>("bf16x3 register-fed (24 MFMA / k-step)");
+    run<1, 1>("bf16x3 + 12 ds_read_b128");
+    run<1, 2>("bf16x3 + 12 ds_read_b128");
+    run<2, 1>("bf16x3 + reads + split VALU (8 fp32 / thread) + 6 ds_write_b128 + barrier");
+    const double s2 = run<2, 2>("bf16x3 + reads + split VALU (8 fp32 / thread) + 6 ds_write_b128 + barrier");
+    run<3, 1>("bf16x3 + reads + split + writes + global loads (A fp32, B pre-split)");
+    const double s3 = run<3, 2>("bf16x3 + reads + split + writes + global loads (A fp32, B pre-split)");
+    runf32<1>();
+    const double f = runf32<2>();
+    printf("ratio: staged bf16x3 loop / f32 MFMA loop = %.2f (LDS-staged), %.2f (with global loads)   [kill criterion: < 1.3]\n", s2 / f, s3 / f);
+    return 0;
+}
