@@ -18,6 +18,9 @@ from . import _lib, nets, ops
 from .nets import Act
 
 
+DECODE_TOPK = "decode.nms_topk"      # launch name of the peak extraction: the one launch the scheduler prefers (plan_schedule)
+
+
 def normalize_state_dict(sd, arch=None):
     """load_model's key fix-up (lib/models/model.py:76-80): strip a leading 'module.'; with `arch`, also map the checkpoint's keys
     onto the graph's (`nets.internal_key`: the stand-alone `resdcn` model has no backbone_model. / head_model. prefixes)."""
@@ -170,6 +173,14 @@ class PlanBuilder(nets.Graph):
     def add(self, kind, name, flops, launch):
         self.launches.append((kind, name, flops * self.B, launch))
 
+    def unit_scale(self, n):
+        """(ones[n], zeros[n]): scale / shift of a split launch that stores raw partial sums -- one pair per width for the whole model
+        (every plan of a FIX_RES=false model shares them through const_cache), not one allocation per split layer."""
+        hit = self.const_cache.get(("unit", n))
+        if hit is None:
+            hit = self.const_cache[("unit", n)] = (torch.ones(n, device=self.dev), torch.zeros(n, device=self.dev))
+        return hit
+
     def add_wino(self, name, flops, x, wp, u, sc, sh, out, cout, act, res=None):
         """One Winograd 3x3 launch -- or, for a map too small to fill the chip (ops.wino_ksplit) and no residual, a split-C
         launch into a workspace of raw partial outputs plus the fixed-order reduction that applies scale / shift / activation.
@@ -184,7 +195,7 @@ class PlanBuilder(nets.Graph):
             ld, M = out.shape[3], B * H * W
             ws = self.pool.take(S * M * ld)
             wst = ws[: S * M * ld].view(S, M, ld)
-            ones, zeros = torch.ones(sc.numel(), device=self.dev), torch.zeros(sc.numel(), device=self.dev)
+            ones, zeros = self.unit_scale(sc.numel())
             self.add("wino", name, flops, ops.conv2d_launch([x], wp, ones, zeros, wst, kh=3, kw=3, stride=1, pad=1, cout=cout, wino=u,
                                                             ksplit=S))
             self.add("sum", name + ".splitc", 0, ops.splitk_reduce_launch(wst, sc, sh, out, cout=cout, act=act))
@@ -224,7 +235,7 @@ class PlanBuilder(nets.Graph):
             ldw, M = wp.shape[0], self.B * Ho * Wo
             ws = self.pool.take(S * M * ldw)
             wst = ws[: S * M * ldw].view(S, M, ldw)
-            ones, zeros = torch.ones(ldw, device=self.dev), torch.zeros(ldw, device=self.dev)
+            ones, zeros = self.unit_scale(ldw)
             self.add("conv", conv, flops, ops.conv2d_launch(srcs, wp, ones, zeros, wst, kh=k, kw=k, stride=stride, pad=pad, cout=ldw, ksplit=S))
             self.add("sum", conv + ".splitk", 0, ops.splitk_reduce_launch(wst, sc, sh, out.t, cout=out.t.shape[3], act=self.act_code(relu)))
             self.pool.give(ws)
@@ -300,7 +311,7 @@ class PlanBuilder(nets.Graph):
             ldw = wp.shape[0]
             ws = self.pool.take(S * self.B * x.H * x.W * ldw)
             wst = ws[: S * self.B * x.H * x.W * ldw].view(S, self.B * x.H * x.W, ldw)
-            ones, zeros = torch.ones(ldw, device=self.dev), torch.zeros(ldw, device=self.dev)
+            ones, zeros = self.unit_scale(ldw)
             self.add("dcn", conv, flops, ops.dcn_v2_launch(x.t, om.t, wp, ones, zeros, wst, cout=ldw, om_sigmoid=True, ksplit=S))
             self.add("sum", conv + ".splitk", 0, ops.splitk_reduce_launch(wst, sc, sh, out.t, cout=out.t.shape[3], act=ops.ACT_RELU))
             self.pool.give(ws)
@@ -535,7 +546,7 @@ class Engine:
             ws = torch.zeros((2, B, 1 + J, K), dtype=torch.float32, device=self.device)
             self.dets = torch.zeros((B, K, 5 + 3 * J), dtype=torch.float32, device=self.device)
         topk, assign = ops.decode_launches(hm, wh, hps, reg, hm_hp, hp_offset, K, ws, self.dets)
-        self.launches = self.emission = self.launches + [("decode", "decode.nms_topk", 0, topk), ("decode", "decode.pose_assign", 0, assign)]
+        self.launches = self.emission = self.launches + [("decode", DECODE_TOPK, 0, topk), ("decode", "decode.pose_assign", 0, assign)]
         self.activation_bytes += 4 * (ws.numel() + self.dets.numel())
         self.decode_k = K
 
@@ -621,7 +632,7 @@ class Engine:
         # the peak extraction (288 small blocks, no MFMA) needs hm / hm_hp only: as soon as those two heads are done it goes beside the
         # remaining head convolutions instead of behind them (a 56 us tail of the step at B = 16 otherwise)
         ll = self.launches if launches is None else launches
-        prefer = [kind == "decode.nms_topk" for (_, kind, _, _) in ll] if os.environ.get("CP_SCHED_PREFER", "1") != "0" else None
+        prefer = [kind == "decode" and name == DECODE_TOPK for (kind, name, _, _) in ll] if os.environ.get("CP_SCHED_PREFER", "1") != "0" else None
         return list_schedule(self.dependencies(launches), durations, nstreams, prefer)
 
     def _run_branches(self, main, nstreams, deps, assign=None):

@@ -179,6 +179,14 @@ def test_bench_single_gpu_line_contract():
     assert any("traffic_ratio" in t for t in roof["templates"].values())
     sus = line["sustained"]
     assert sus["replays"] >= 1000 and 0.8 * line["value"] < sus["images_per_sec"] < 1.2 * line["value"]
+    # the kernels this line timed, for tests/test_engine_hip.py::test_timed_configuration_parity of the SAME pytest session (it runs
+    # later: "test_dist_gpu" < "test_engine_hip") -- tested kernels == timed kernels as a hard assertion again
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "timed_kernels_dla_34.json"), "w") as f:
+            json.dump({"kernels": sorted(roof["kernels"]), "from": "bench.py --gpus 1 --steps 5 --warmup 2 --no-cpu-baseline"}, f, indent=1)
+    except OSError as e:
+        print("could not write the timed-kernel list:", e)
     sb = line["other_configs"]["res_50_b8_split_bf16"]
     assert "error" not in sb, sb
     assert "igemm_bf16x3_kernel" in sb["templates"] and "CP_SPLIT_BF16=1" in sb["mode"] and sb["images_per_sec"] > 0

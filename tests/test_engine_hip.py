@@ -563,7 +563,9 @@ def test_timed_configuration_parity(arch, B):
     tile choices of this size.  Reference side: MultiPoseDetector.process, lib/detectors/multi_pose.py:29-60.
     (a) images 0, B/2-1, B-1 against the CPU oracle network: the north-star 1e-3 bar on every head;
     (b) dets of ALL images bit-equal to the oracle decode of the engine's own head maps;
-    (c) the kernel instantiations this engine dispatched to are WRITTEN to gpurun_out/tested_kernels_<arch>.json;
+    (c) the kernel instantiations this engine dispatched to equal -- hard assertion -- the `roofline.kernels` of the bench line that
+        tests/test_dist_gpu.py::test_bench_single_gpu_line_contract produced earlier in the SAME pytest session (when that file is
+        there and fresh); they are also WRITTEN to gpurun_out/tested_kernels_<arch>.json;
         tools/gpu_check.sh compares that list with `roofline.kernels` of the bench line of the same box session (the tested kernels
         ARE the timed kernels).  Round 3 asserted against the committed profiles/bench_line.json here, which made the driver's test
         run depend on a hand-refreshed file: a stale file now only prints a note;
@@ -607,6 +609,14 @@ def test_timed_configuration_parity(arch, B):
             json.dump({"arch": arch, "batch": B, "kernels": kernels}, f, indent=1)
     except OSError as e:
         print("could not write the tested-kernel list:", e)
+    # same-session hard check: tests/test_dist_gpu.py::test_bench_single_gpu_line_contract ran bench.py a few minutes ago
+    # in this pytest session and left the kernel list of THAT line; the kernels parity-tested here must be the kernels it timed
+    import time
+    tk = os.path.join(root, "gpurun_out", "timed_kernels_dla_34.json")
+    if arch == "dla_34" and os.path.exists(tk) and time.time() - os.path.getmtime(tk) < 3600:
+        timed = json.load(open(tk))["kernels"]
+        assert kernels == timed, "bench.py timed other kernels than the ones parity-tested here: %s" % sorted(set(kernels) ^ set(timed))
+        print("tested kernels == timed kernels (bench line of this session): %d instantiations" % len(kernels))
     if arch == "dla_34" and os.path.exists(BENCH_LINE):
         timed = sorted(json.load(open(BENCH_LINE))["roofline"]["kernels"])
         if kernels != timed:

@@ -17,7 +17,7 @@ SHAPES = [("GO/NO-GO 1x1 256->256 @64 B8", 8, 64, 256, 256, 1, 1),
           ("r50 l4 3x3s2 512->512 @32 B8", 8, 32, 512, 512, 3, 2), ("r50 ds 1x1s2 256->512 @128 B8", 8, 128, 256, 512, 1, 2),
           ("dla root 1x1 128->64 @128 B16", 16, 128, 128, 64, 1, 1), ("dla root 1x1 256->128 @64 B16", 16, 64, 256, 128, 1, 1),
           ("dla root 1x1 896->256 @32 B16", 16, 32, 896, 256, 1, 1), ("dla s2 3x3 64->128 @128 B16", 16, 128, 64, 128, 3, 2),
-          ("hrnet fuse 1x1 64->32 @64 B8", 8, 64, 64, 32, 1, 1), ("hrnet s2 3x3 32->64 @128 B8", 8, 128, 32, 64, 3, 2),
+          ("hrnet fuse 1x1 128->64 @32 B8", 8, 32, 128, 64, 1, 1), ("hrnet s2 3x3 32->64 @128 B8", 8, 128, 32, 64, 3, 2),
           ("big 1x1 1024->1024 @64 B8", 8, 64, 1024, 1024, 1, 1)]
 if len(sys.argv) > 1 and sys.argv[1] == "quick":
     SHAPES = SHAPES[:3]
@@ -68,7 +68,8 @@ for name, B, H, Ci, Co, k, s in SHAPES:
             t32 = t
         else:
             ratios.append((name, mode, t32 / t))
-    best = max(r for n, m, r in ratios if n == name)
+    best = max([r for n, m, r in ratios if n == name] or [0.0])
+    errs += [float("nan")] * (2 - len(errs))
     print("%-34s %-22s %-30s %-30s %.2e | %.2e   best x%.2f" % (name, cols[0], cols[1], cols[2] if len(cols) > 2 else "-", errs[0], errs[1], best))
 go = max(r for n, m, r in ratios if n.startswith("GO/NO-GO")) if ratios else 0.0
 print("\nGO/NO-GO GEMM: split-bf16 / f32 MFMA speed ratio %.2f (kill criterion < 1.3): %s" % (go, "GO" if go >= 1.3 else "NO-GO"))
