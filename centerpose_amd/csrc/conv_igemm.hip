@@ -17,22 +17,21 @@ struct PixSlot {
     int iy0, ix0;
 };
 
+// one block of the launch described by `a`: tile `tile` (already XCD-remapped) of `nblocks`
 template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, bool STEM>
-__global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a)
+__device__ __forceinline__ void igemm_conv_block(const ConvArgs& a, int tile, int nblocks, float* smem)
 {
     using T = IgTile<BM, BN, WAVES_M, WAVES_N, MF>;
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As0 = smem;                       // [2][BM][IG_LDK]
     float* Bs0 = smem + 2 * T::A_FLOATS;     // [2][BN][IG_LDK]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-    int tile = ig_xcd_remap(blockIdx.x, gridDim.x);
     // per-block view of the fields that differ between the sub-convolutions of a fused sub-pixel deconvolution (nsub = 4):
     // a 2048 -> 256 deconv at 16x16 is 4 x 128 blocks with 512 k-steps each - half the CUs idle per launch when run one by one
     const float* wsub = a.w;
     int pys = a.py, pxs = a.px, ooys = 0, ooxs = 0;
     if (a.nsub > 1) {
-        const int per = gridDim.x / a.nsub, sub = tile / per;
+        const int per = nblocks / a.nsub, sub = tile / per;
         tile -= sub * per;
         wsub += (size_t)sub * a.ldw * a.K;
         pys -= sub >> 1; pxs -= sub & 1;
@@ -208,6 +207,50 @@ __global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a
         e.out = a.out + (size_t)ksp * a.M * a.outLd;
         ig_epilogue<T, BM, BN, MF>(e, smem, m0, n0, wm0, wn0, lane, tid, acc, ooys, ooxs);
     } else ig_epilogue<T, BM, BN, MF>(a, smem, m0, n0, wm0, wn0, lane, tid, acc, ooys, ooxs);
+}
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, int MF, bool STEM>
+__global__ __launch_bounds__(IG_THREADS) void igemm_conv_kernel(const ConvArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    igemm_conv_block<BM, BN, WAVES_M, WAVES_N, MF, STEM>(a, ig_xcd_remap(blockIdx.x, gridDim.x), gridDim.x, smem);
+}
+
+// Up to IG_GROUP_MAX INDEPENDENT single-source NHWC convolutions in ONE launch on the 64 x 64 tile: HRNet's fuse layers
+// (pose_higher_hrnet.py:169-212: per module up to six 1x1 convs at 16x16 .. 64x64 and six stride-2 3x3 convs, 13-29 us each one by one
+// on 16-256 blocks -- the chip is mostly idle, and the two capture streams cannot run more than two of them side by side).  Member k owns
+// the blocks [first[k], first[k + 1]); members are ordered longest block (most k-steps) first so the short ones fill the tail.
+#define IG_GROUP_MAX 8
+struct IgMember {
+    const float* src; const float* w; const float* scale; const float* shift; const float* res; float* out;
+    int C, srcLd, B, H, W, Ho, Wo, kh, kw, sy, sx, py, px, K, ldw, resLd, outLd, Cout, act, pad_;
+};
+struct IgGroup {
+    IgMember m[IG_GROUP_MAX];
+    int first[IG_GROUP_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(IG_THREADS) void igemm_conv_group_kernel(const IgGroup g)
+{
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int t = blockIdx.x;
+    int k = 0;
+    while (k + 1 < g.n && t >= g.first[k + 1]) ++k;            // scalar
+    const IgMember& mm = g.m[k];
+    ConvArgs a;
+    a.src[0] = mm.src; a.src[1] = a.src[2] = a.src[3] = nullptr;
+    a.srcC[0] = mm.C; a.srcC[1] = a.srcC[2] = a.srcC[3] = 0;
+    a.srcLd[0] = mm.srcLd; a.srcLd[1] = a.srcLd[2] = a.srcLd[3] = 0;
+    a.nsrc = 1; a.Ctot = mm.C;
+    a.B = mm.B; a.H = mm.H; a.W = mm.W; a.Ho = mm.Ho; a.Wo = mm.Wo; a.M = mm.B * mm.Ho * mm.Wo;
+    a.kh = mm.kh; a.kw = mm.kw; a.sy = mm.sy; a.sx = mm.sx; a.py = mm.py; a.px = mm.px;
+    a.K = mm.K; a.w = mm.w; a.ldw = mm.ldw; a.scale = mm.scale; a.shift = mm.shift; a.res = mm.res; a.resLd = mm.resLd;
+    a.out = mm.out; a.outLd = mm.outLd; a.Cout = mm.Cout; a.outNCHW = 0; a.OH = mm.Ho; a.OW = mm.Wo;
+    a.osy = a.osx = 1; a.ooy = a.oox = 0; a.act = mm.act;
+    a.om = nullptr; a.omLd = 0; a.omMaskOff = 0; a.omSigmoid = 0; a.dily = a.dilx = 1; a.ksplit = 1; a.dg = 1; a.nsub = 1;
+    // no XCD remap across members (it would hand each XCD one member's blocks, cf. conv3x3_wino24_group_kernel); inside a member
+    // consecutive blocks share activation rows and go round-robin over the XCDs anyway
+    igemm_conv_block<64, 64, 2, 2, 32, false>(a, t - g.first[k], g.first[k + 1] - g.first[k], smem);
 }
 
 // `occ` (tile code digit 8, tuning / experiments): at most that many blocks per CU, enforced by asking for 160 KiB / occ of dynamic
@@ -405,6 +448,42 @@ extern "C" int cp_head3x3_1x1_f32(const cp_conv_desc* d, const float* src, const
     CP_CHECK_ARG(rc >= 0, "head3x3_1x1: shape not eligible (C = 64, Cmid %% 32 == 0, ReLU, n2 <= 34, 16-byte aligned operands)");
     if (rc) return rc;
     CP_CHECK_LAUNCH("head3x3_1x1 kernel");
+    return 0;
+}
+
+// Up to 8 INDEPENDENT generic convolutions in ONE launch (HRNet's fuse layers): d[i], src[i], w[i], scale[i], shift[i], res[i] (may be
+// NULL), out[i] describe member i exactly as for cp_conv2d_f32 with ONE NHWC source, NHWC dense output, ldw % 64 == 0, no split-K, no
+// sub-pixel deconvolution; the members must not alias each other's outputs.
+extern "C" int cp_conv2d_group_f32(const cp_conv_desc* d, int n, const float* const* src, const float* const* w, const float* const* scale,
+                                   const float* const* shift, const float* const* res, float* const* out, void* stream)
+{
+    CP_CHECK_ARG(d && src && w && scale && shift && res && out && n >= 1 && n <= IG_GROUP_MAX, "conv2d_group: 1..%d members, no null arrays", IG_GROUP_MAX);
+    using T = IgTile<64, 64, 2, 2, 32>;
+    IgGroup g;
+    g.n = n;
+    long long total = 0;
+    for (int i = 0; i < n; ++i) {
+        ConvArgs a;
+        const float* srcs[1] = {src[i]};
+        CP_CHECK_ARG(d[i].nsrc == 1 && !d[i].inNCHW && !d[i].outNCHW && d[i].nsub <= 1 && d[i].ksplit <= 1 && d[i].ldw % 64 == 0,
+                     "conv2d_group: member %d: one NHWC source, NHWC output, ldw %% 64 == 0, no nsub / ksplit", i);
+        CP_CHECK_ARG(d[i].osy == 1 && d[i].osx == 1 && d[i].ooy == 0 && d[i].oox == 0 && d[i].OH == d[i].Ho && d[i].OW == d[i].Wo,
+                     "conv2d_group: member %d: dense output expected", i);
+        if (int rc = conv_args_from_desc(&d[i], srcs, w[i], scale[i], shift[i], res[i], out[i], a)) return rc;
+        IgMember& m = g.m[i];
+        m.src = a.src[0]; m.w = a.w; m.scale = a.scale; m.shift = a.shift; m.res = a.res; m.out = a.out;
+        m.C = a.srcC[0]; m.srcLd = a.srcLd[0]; m.B = a.B; m.H = a.H; m.W = a.W; m.Ho = a.Ho; m.Wo = a.Wo;
+        m.kh = a.kh; m.kw = a.kw; m.sy = a.sy; m.sx = a.sx; m.py = a.py; m.px = a.px; m.K = a.K; m.ldw = a.ldw; m.resLd = a.resLd;
+        m.outLd = a.outLd; m.Cout = a.Cout; m.act = a.act; m.pad_ = 0;
+        g.first[i] = (int)total;
+        total += (long long)cp_cdiv(a.M, 64) * (a.ldw / 64);
+    }
+    for (int i = n; i <= IG_GROUP_MAX; ++i) g.first[i] = (int)total;
+    for (int i = n; i < IG_GROUP_MAX; ++i) g.m[i] = g.m[0];
+    CP_CHECK_ARG(total < (1ll << 31), "conv2d_group: grid %lld too large", total);
+    hipLaunchKernelGGL(igemm_conv_group_kernel, dim3((unsigned)total), dim3(IG_THREADS), T::NHWC_BYTES, (hipStream_t)stream, g);
+    cp_note_kernel("igemm_conv_group_kernel");
+    CP_CHECK_LAUNCH("igemm_conv_group_kernel");
     return 0;
 }
 

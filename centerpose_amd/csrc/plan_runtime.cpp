@@ -19,6 +19,8 @@ int cp_conv3x3_winograd_f32(const cp_conv_desc*, const float*, const float*, con
 int cp_dcn_v2_f32(const cp_dcn_desc*, const float*, const float*, const float*, const float*, const float*, float*, void*);
 int cp_conv3x3_winograd24_group_f32(const cp_conv_desc*, int, const float* const*, const float* const*, const float* const*, const float* const*,
                                     const float* const*, float* const*, void*);
+int cp_conv2d_group_f32(const cp_conv_desc*, int, const float* const*, const float* const*, const float* const*, const float* const*,
+                        const float* const*, float* const*, void*);
 int cp_stem7x7_f32(const float*, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, void*);
 int cp_maxpool2d_nhwc_f32(const float*, int, float*, int, int, int, int, int, int, int, int, void*);
 int cp_dw_deconv_add_nhwc_f32(const float*, int, const float*, const float*, int, float*, int, int, int, int, int, int, void*);
@@ -42,7 +44,7 @@ int cp_decode_assign_f32(const float*, const float*, const float*, const float*,
 namespace {
 
 enum { FN_CONV = 1, FN_WINO = 2, FN_DCN = 3, FN_STEM7 = 4, FN_POOL = 5, FN_UPADD = 6, FN_SUMUP = 7, FN_DWCONV = 8, FN_AVGPOOL = 9,
-       FN_SCALEADD = 10, FN_SHUFFLE = 11, FN_HEAD = 12, FN_TOPK = 13, FN_ASSIGN = 14, FN_SPLITK = 15, FN_WINO24G = 16 };   // ops.FN_IDS
+       FN_SCALEADD = 10, FN_SHUFFLE = 11, FN_HEAD = 12, FN_TOPK = 13, FN_ASSIGN = 14, FN_SPLITK = 15, FN_WINO24G = 16, FN_CONVG = 17 };   // ops.FN_IDS
 enum { REF_NULL = 0, REF_BUF = 1, REF_CONST = 2 };
 
 struct Op {
@@ -109,6 +111,11 @@ int run_op(const Op& o, hipStream_t s)
                                                    reinterpret_cast<const float* const*>(P.data() + 4), reinterpret_cast<const float* const*>(P.data() + 8),
                                                    reinterpret_cast<const float* const*>(P.data() + 12), reinterpret_cast<const float* const*>(P.data() + 16),
                                                    reinterpret_cast<float* const*>(P.data() + 20), s);
+        case FN_CONVG:        // ptrs: src x8, w x8, scale x8, shift x8, res x8, out x8, (the storage all outputs live in); ints: n; desc: 8 cp_conv_desc
+            return cp_conv2d_group_f32(reinterpret_cast<const cp_conv_desc*>(o.desc.data()), I[0], reinterpret_cast<const float* const*>(P.data()),
+                                       reinterpret_cast<const float* const*>(P.data() + 8), reinterpret_cast<const float* const*>(P.data() + 16),
+                                       reinterpret_cast<const float* const*>(P.data() + 24), reinterpret_cast<const float* const*>(P.data() + 32),
+                                       reinterpret_cast<float* const*>(P.data() + 40), s);
         case FN_STEM7:
             return cp_stem7x7_f32(P[0], P[1], P[2], P[3], P[4], I[0], I[1], I[2], I[3], I[4], I[5], I[6], s);
         case FN_POOL:
@@ -148,6 +155,7 @@ bool arity_ok(const Op& o)
         case FN_WINO: return o.ptrs.size() == 6 && (int)o.desc.size() == cp_sizeof_conv_desc();
         case FN_DCN: return o.ptrs.size() == 6 && (int)o.desc.size() == cp_sizeof_dcn_desc();
         case FN_WINO24G: return o.ptrs.size() == 25 && o.ints.size() == 1 && o.ints[0] >= 1 && o.ints[0] <= 4 && (int)o.desc.size() == 4 * cp_sizeof_conv_desc();
+        case FN_CONVG: return o.ptrs.size() == 49 && o.ints.size() == 1 && o.ints[0] >= 1 && o.ints[0] <= 8 && (int)o.desc.size() == 8 * cp_sizeof_conv_desc();
         case FN_STEM7: return o.ptrs.size() == 5 && o.ints.size() == 7;
         case FN_POOL: return o.ptrs.size() == 2 && o.ints.size() == 9;
         case FN_UPADD: return o.ptrs.size() == 4 && o.ints.size() == 8;

@@ -276,6 +276,44 @@ class PlanBuilder(nets.Graph):
         self.add("wino24", "group:" + members[0][1], flops, ops.conv3x3_group_launch(recs, slot[:off]))
         return outs
 
+    def emit_conv_batch(self, members):
+        """Independent single-source convs of any kernel size / stride (HRNet: all first -- then all second, third -- convs of a
+        module's fuse paths, pose_higher_hrnet.py:169-212) as ONE grouped launch of the generic 64 x 64 implicit-GEMM tile per up to
+        eight members (CP_GROUP=0 / CP_FUSE_GROUP=0: one launch each, with their own tile / split-K rules).  One by one these are
+        13-29 us launches of 16-256 blocks on a 256-CU chip; weights / scale / shift are padded to 64 output rows for the shared tile
+        (zero rows: the padding channels of the output are written as zeros, as everywhere).  All outputs of a launch live in ONE
+        pool slot (`Engine.dependencies` tracks one output storage per launch record)."""
+        ok = os.environ.get("CP_GROUP", "1") != "0" and os.environ.get("CP_FUSE_GROUP", "1") != "0" and len(members) >= 2 and \
+            all(not x.split and x.t.shape[3] % 16 == 0 and not ops.wino_eligible(x.t.shape[3], k, stride, pad, 1) and not (k == 3 and x.t.shape[3] == 16)
+                for x, _, _, _, k, stride, pad, _ in members)
+        if not ok:
+            return super().emit_conv_batch(members)
+        outs = []
+        for c0 in range(0, len(members), ops.GROUP_MAX):
+            chunk = members[c0:c0 + ops.GROUP_MAX]
+            if len(chunk) == 1:
+                outs += super().emit_conv_batch(chunk)
+                continue
+            dims = [((x.H + 2 * pad - k) // stride + 1, (x.W + 2 * pad - k) // stride + 1) for x, _, _, _, k, stride, pad, _ in chunk]
+            sizes = [self.B * h * w * ops.round_up(m[3], 16) for (h, w), m in zip(dims, chunk)]
+            slot = self.pool.take(sum(sizes))
+            holder = Act(1, 1, 1, slot)
+            weakref.finalize(holder, self.pool.give, slot)      # the slot returns to the pool when the last member activation is dropped
+            recs, off, flops = [], 0, 0
+            for (x, conv, bn, co, k, stride, pad, relu), (h, w), n in zip(chunk, dims, sizes):
+                cp = ops.round_up(co, 16)
+                out = Act(h, w, co, slot[off:off + n].view(self.B, h, w, cp), parent=holder)
+                off += n
+                wp = ops.pack_conv_weight(self.expand_in(self.w(conv + ".weight"), [x]))
+                sc, sh = ops.fold_bn(co, self.bn(bn), None, self.dev)
+                ldw = ops.round_up(wp.shape[0], 64)
+                recs.append(dict(x=x.t, wp=ops.pad_rows(wp, ldw), scale=ops.pad_vec(sc, ldw), shift=ops.pad_vec(sh, ldw), out=out.t, cout=cp,
+                                 k=k, stride=stride, pad=pad, act=self.act_code(relu)))
+                flops += 2 * h * w * co * x.C * k * k
+                outs.append(out)
+            self.add("conv", "group:" + chunk[0][1], flops, ops.conv2d_group_launch(recs, slot[:off]))
+        return outs
+
     def emit_maxpool(self, x, k, s, p):
         # a DLA tree pools the same input at every recursion level (pose_dla_dcn.py:197-198,207): emit it once.  Weak
         # references only -- the cache must neither keep a dead activation's storage out of the pool nor match a
@@ -769,7 +807,9 @@ class Engine:
     def launch_bytes(self, launches=None):
         """Algorithmic (compulsory) HBM bytes of every launch: each tensor argument once -- inputs, residual, the weights
         the kernel actually reads (Winograd launches carry U, not the direct weights), output."""
-        return [sum(4 * t.numel() for t in launch.tensors if t is not None)
+        # (a grouped launch lists every member's output AND the storage they all live in: the latter is not counted again)
+        grouped = ("cp_conv3x3_winograd24_group_f32", "cp_conv2d_group_f32")
+        return [sum(4 * t.numel() for t in (launch.tensors[:-1] if launch.fn in grouped else launch.tensors) if t is not None)
                 for _, _, _, launch in (self.launches if launches is None else launches)]
 
     def profile(self, iters=5):

@@ -68,6 +68,11 @@ class Graph:
         may run as one launch (HRNet's parallel branches).  Default: one after the other."""
         return [self.emit_conv([x], conv, bn, False, co, 3, 1, 1, relu, res, False) for x, conv, bn, co, relu, res in members]
 
+    def emit_conv_batch(self, members):
+        """members: [(x, conv, bn, co, k, stride, pad, relu)] -- INDEPENDENT single-source conv + BN (+ ReLU) launches of any kernel size /
+        stride that may run as one launch (the fuse layers of an HRNet module).  Default: one after the other."""
+        return [self.emit_conv([x], conv, bn, False, co, k, stride, pad, relu, None, False) for x, conv, bn, co, k, stride, pad, relu in members]
+
     def emit_dcn(self, x, conv, bn, co):
         return Act(x.H, x.W, co)
 
@@ -284,22 +289,40 @@ class Graph:
             q = ["%s.branches.%d.%d" % (p, i, b) for i in range(nb)]
             hs = self.emit_conv_group([(xs[i], q[i] + ".conv1", q[i] + ".bn1", chans[i], True, None) for i in range(nb)])
             xs = self.emit_conv_group([(hs[i], q[i] + ".conv2", q[i] + ".bn2", chans[i], True, xs[i]) for i in range(nb)])
-        outs = []
-        for i in range(nb if multi_scale_output else 1):
-            terms, shifts = [], []
+        # Fuse layers (pose_higher_hrnet.py:169-212, forward :224-235).  Every path (i, j) is a chain of convs that starts from a branch
+        # output: one 1x1 conv (j > i, then nearest-upsampled inside the sum) or i - j stride-2 3x3 convs (j < i).  The chains are walked
+        # LEVEL by level -- all first convs of a module are independent (`emit_conv_batch`: one launch), then all second convs, ... --
+        # instead of path by path; parameters are registered path by path first, in the reference module's order.
+        nout = nb if multi_scale_output else 1
+        chains = {}
+        for i in range(nout):
             for j in range(nb):
-                if j == i:
-                    terms.append(xs[j]); shifts.append(0)
-                elif j > i:
+                if j > i:
                     q = "%s.fuse_layers.%d.%d" % (p, i, j)
-                    terms.append(self.conv(xs[j], q + ".0", q + ".1", chans[i], 1)); shifts.append(j - i)
-                else:
-                    t = xs[j]
+                    chains[(i, j)] = [(q + ".0", q + ".1", chans[j], chans[i], 1, 1, 0, False)]
+                elif j < i:
+                    chains[(i, j)] = []
                     for k in range(i - j):
                         q = "%s.fuse_layers.%d.%d.%d" % (p, i, j, k)
                         last = k == i - j - 1
-                        t = self.conv(t, q + ".0", q + ".1", chans[i] if last else chans[j], 3, 2, 1, relu=not last)
-                    terms.append(t); shifts.append(0)
+                        chains[(i, j)].append((q + ".0", q + ".1", chans[j], chans[i] if last else chans[j], 3, 2, 1, not last))
+                if (i, j) in chains:
+                    h, w = xs[j].H, xs[j].W
+                    for conv, bn, ci, co, k, st, pd, _ in chains[(i, j)]:
+                        self.p_conv(conv, co, ci, k)
+                        self.p_bn(bn, co)
+                        h, w = (h + 2 * pd - k) // st + 1, (w + 2 * pd - k) // st + 1
+                        self.flops += 2 * h * w * co * ci * k * k
+        cur = {ij: xs[ij[1]] for ij in chains}
+        for lvl in range(max([len(c) for c in chains.values()] or [0])):
+            todo = [ij for ij in sorted(chains) if len(chains[ij]) > lvl]
+            res = self.emit_conv_batch([(cur[ij],) + tuple(chains[ij][lvl][q] for q in (0, 1, 3, 4, 5, 6, 7)) for ij in todo])
+            for ij, r in zip(todo, res):
+                cur[ij] = r
+        outs = []
+        for i in range(nout):
+            terms = [xs[j] if j == i else cur[(i, j)] for j in range(nb)]
+            shifts = [j - i if j > i else 0 for j in range(nb)]
             outs.append(self.emit_sum_up(terms, shifts, True))
         return outs
 

@@ -82,6 +82,9 @@ def marshal(fn, desc, ptrs, ints):
     if fn == "cp_conv3x3_winograd24_group_f32":   # desc: ConvDesc x 4; ptrs: src x4, u x4, scale x4, shift x4, res x4, out x4, whole; ints: n
         arr = lambda k: (ctypes.c_void_p * 4)(*[p.value for p in ptrs[4 * k:4 * k + 4]])
         return [d, ints[0]] + [arr(k) for k in range(6)]
+    if fn == "cp_conv2d_group_f32":               # desc: ConvDesc x 8; ptrs: src x8, w x8, scale x8, shift x8, res x8, out x8, whole; ints: n
+        arr = lambda k: (ctypes.c_void_p * 8)(*[p.value for p in ptrs[8 * k:8 * k + 8]])
+        return [d, ints[0]] + [arr(k) for k in range(6)]
     if fn == "cp_head3x3_1x1_f32":                # ptrs: src, u, scale, shift, w2, b2, out2; ints: n2, ld2, act2
         return [d] + ptrs + ints
     if fn == "cp_stem7x7_f32":                    # ptrs: x, w, scale, shift, out; ints: B, H, W, Cout, stride, outLd, relu
@@ -115,7 +118,7 @@ def marshal(fn, desc, ptrs, ints):
 FN_IDS = {"cp_conv2d_f32": 1, "cp_conv3x3_winograd_f32": 2, "cp_dcn_v2_f32": 3, "cp_stem7x7_f32": 4,
           "cp_maxpool2d_nhwc_f32": 5, "cp_dw_deconv_add_nhwc_f32": 6, "cp_sum_up_nhwc_f32": 7, "cp_dwconv2d_nhwc_f32": 8,
           "cp_global_avgpool_nhwc_f32": 9, "cp_scale_add_nhwc_f32": 10, "cp_shuffle_concat_nhwc_f32": 11, "cp_head3x3_1x1_f32": 12,
-          "cp_decode_topk_f32": 13, "cp_decode_assign_f32": 14, "cp_splitk_reduce_f32": 15, "cp_conv3x3_winograd24_group_f32": 16}
+          "cp_decode_topk_f32": 13, "cp_decode_assign_f32": 14, "cp_splitk_reduce_f32": 15, "cp_conv3x3_winograd24_group_f32": 16, "cp_conv2d_group_f32": 17}
 
 
 def pad_rows(t, ldw):
@@ -302,6 +305,30 @@ def conv3x3_group_launch(members, whole):
             assert t is None or k in (0, 4, 5) or t.is_contiguous()
         assert mm["out"].untyped_storage().data_ptr() == whole.untyped_storage().data_ptr()
     return Launch("cp_conv3x3_winograd24_group_f32", d, [t for col in cols for t in col] + [whole], [len(members)])
+
+
+ConvDesc8 = ConvDesc * 8
+GROUP_MAX = 8
+
+
+def conv2d_group_launch(members, whole):
+    """Up to eight independent single-source NHWC convolutions on the generic 64 x 64 implicit-GEMM tile in ONE launch (HRNet's fuse
+    layers).  members: list of dicts {x, wp, scale, shift, out, cout, k, stride, pad, act, res}; wp / scale / shift padded to
+    ldw % 64 == 0; `whole`: the one storage every `out` is a view of.  Ordered longest block (most k-steps) first."""
+    assert 1 <= len(members) <= GROUP_MAX
+    members = sorted(members, key=lambda mm: -mm["wp"].shape[1])
+    d = ConvDesc8()
+    cols = [[None] * GROUP_MAX for _ in range(6)]
+    for i, mm in enumerate(members):
+        assert mm["wp"].shape[0] % 64 == 0
+        one = conv2d_launch([mm["x"]], mm["wp"], mm["scale"], mm["shift"], mm["out"], kh=mm["k"], kw=mm["k"], stride=mm["stride"],
+                            pad=mm["pad"], cout=mm["cout"], act=mm["act"], res=mm.get("res"), split_bf16=False)
+        ctypes.memmove(ctypes.addressof(d[i]), ctypes.addressof(one.desc), ctypes.sizeof(ConvDesc))
+        for k, t in enumerate((mm["x"], mm["wp"], mm["scale"], mm["shift"], mm.get("res"), mm["out"])):
+            cols[k][i] = t
+            assert t is None or k in (0, 4, 5) or t.is_contiguous()
+        assert mm["out"].untyped_storage().data_ptr() == whole.untyped_storage().data_ptr()
+    return Launch("cp_conv2d_group_f32", d, [t for col in cols for t in col] + [whole], [len(members)])
 
 
 def head3x3_1x1_eligible(x, hc, n2):

@@ -65,7 +65,7 @@ def checksum(data):
 REF_NULL, REF_BUF, REF_CONST = 0, 1, 2
 FN_NAMES = {v: k for k, v in ops.FN_IDS.items()}
 DESC_TYPES = {"cp_conv2d_f32": ops.ConvDesc, "cp_conv3x3_winograd_f32": ops.ConvDesc, "cp_dcn_v2_f32": ops.DcnDesc,
-              "cp_conv3x3_winograd24_group_f32": ops.ConvDesc4,
+              "cp_conv3x3_winograd24_group_f32": ops.ConvDesc4, "cp_conv2d_group_f32": ops.ConvDesc8,
               "cp_head3x3_1x1_f32": ops.ConvDesc}
 
 

@@ -64,6 +64,13 @@ typedef struct cp_conv_desc {
 int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, const float* w, const float* scale, const float* shift,
                   const float* res, float* out, void* stream);
 
+/* Up to 8 INDEPENDENT convolutions of the cp_conv2d_f32 kind in ONE launch: the fuse layers of an HRNet module
+ * (pose_higher_hrnet.py:169-212: the 1x1 convs of the up paths and the stride-2 3x3 convs of the down paths read only the branch
+ * outputs, 16-256 blocks each).  d[i], src[i], w[i], scale[i], shift[i], res[i] (may be NULL), out[i]: member i as for
+ * cp_conv2d_f32 with nsrc = 1, NHWC in / dense NHWC out, ldw % 64 == 0, nsub <= 1, ksplit <= 1; outputs must not alias. */
+int cp_conv2d_group_f32(const cp_conv_desc* d, int n, const float* const* src, const float* const* w, const float* const* scale,
+                        const float* const* shift, const float* const* res, float* const* out, void* stream);
+
 /* Opt-in fp32-EQUIVALENT mode of cp_conv2d_f32 on the bf16 matrix pipe (conv_igemm_bf16x3.hip; never the default, the reference's
  * arithmetic is fp32 end to end: DCNv2/src/cuda/dcn_v2_cuda.cu:58): every fp32 operand is three bf16 terms (8+8+8 significand bits,
  * exact), six bf16 MFMAs with fp32 accumulate per product tile, dropped terms <= 2^-24 relative.  Activations are split in the

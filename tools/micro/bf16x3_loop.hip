@@ -6,6 +6,8 @@
 //   MODE 0  register-fed (pipe ceiling)            MODE 1  + 12 ds_read_b128 (3 terms x (2 A + 2 B) fragments)
 //   MODE 2  + split of 8 fresh fp32 activations per thread (v_cvt_pk_bf16_f32 / v_pk_add_f32) + 6 ds_write_b128 + barrier
 //   MODE 3  + the k-step's global loads (2 float4 A + 3 uint4 pre-split B per thread, L2-resident)
+//   MODE 4  as 3, software-pipelined: the split of the NEXT k-step's activations (loaded one iteration earlier) is interleaved with
+//           the MFMAs (one split2 pair per output tile), the loads for the k-step after that are issued behind the LDS writes
 // The last line is the f32 MFMA loop of mfma_peak.hip (LDS-fed, same process) = "the fp32 loop" of the kill criterion.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -66,11 +68,17 @@ __global__ __launch_bounds__(256, BPC) void k(float* out, const float* __restric
                 }
         }
         __builtin_amdgcn_sched_barrier(0);
+        unsigned q1[4], q2[4], q3[4];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                if (MODE >= 3 && i == 1 && j == 0) {          // next k-step's loads from inside the MFMA block
+                if (MODE >= 4) {                               // a quarter of the next k-step's split beside this tile's six MFMAs
+                    const int e = i * 2 + j;
+                    const float x0 = e == 0 ? a0.x : e == 1 ? a0.z : e == 2 ? a1.x : a1.z, x1 = e == 0 ? a0.y : e == 1 ? a0.w : e == 2 ? a1.y : a1.w;
+                    split2(x0, x1, q1[e], q2[e], q3[e]);
+                }
+                if (MODE == 3 && i == 1 && j == 0) {          // next k-step's loads from inside the MFMA block
                     const int ko = (it & 63) * 16;
                     a0 = *(const __attribute__((address_space(1))) v4f*)(pa + ko);
                     a1 = *(const __attribute__((address_space(1))) v4f*)(pa + ko + 4);
@@ -85,15 +93,16 @@ __global__ __launch_bounds__(256, BPC) void k(float* out, const float* __restric
                 acc[i][j] = mm(af[i][0], bf[j][1], acc[i][j]);
                 acc[i][j] = mm(af[i][0], bf[j][0], acc[i][j]);
             }
-        __builtin_amdgcn_sched_barrier(0);
+        if (MODE < 4) __builtin_amdgcn_sched_barrier(0);
         if (MODE >= 2) {
             unsigned* An = lds + (cur ^ 1) * 256 * LDR;
             unsigned* Bn = An + 128 * LDR;
             if (MODE == 2) { a0 += 0.25f; a1 *= 1.0001f; b0 += 1u; }
             v4u t1, t2, t3, u1, u2, u3;
-            unsigned q1[4], q2[4], q3[4];
-            split2(a0.x, a0.y, q1[0], q2[0], q3[0]); split2(a0.z, a0.w, q1[1], q2[1], q3[1]);
-            split2(a1.x, a1.y, q1[2], q2[2], q3[2]); split2(a1.z, a1.w, q1[3], q2[3], q3[3]);
+            if (MODE < 4) {
+                split2(a0.x, a0.y, q1[0], q2[0], q3[0]); split2(a0.z, a0.w, q1[1], q2[1], q3[1]);
+                split2(a1.x, a1.y, q1[2], q2[2], q3[2]); split2(a1.z, a1.w, q1[3], q2[3], q3[3]);
+            }
             t1 = (v4u){q1[0], q1[1], q1[2], q1[3]}; t2 = (v4u){q2[0], q2[1], q2[2], q2[3]}; t3 = (v4u){q3[0], q3[1], q3[2], q3[3]};
             unsigned* ar = An + (tid >> 1) * LDR + (tid & 1) * 4;
             *reinterpret_cast<v4u*>(ar) = t1; *reinterpret_cast<v4u*>(ar + 8) = t2; *reinterpret_cast<v4u*>(ar + 16) = t3;
@@ -102,6 +111,21 @@ __global__ __launch_bounds__(256, BPC) void k(float* out, const float* __restric
             for (int s = 0; s < 3; ++s) {
                 const int idx = tid + s * 256;
                 *reinterpret_cast<v4u*>(Bn + (idx / 6) * LDR + (idx % 6) * 4) = s == 0 ? u1 : s == 1 ? u2 : u3;
+            }
+            if (MODE >= 4) {                                   // loads for the k-step after next: a whole iteration to arrive
+                const int ko = (it & 63) * 16;
+                a0 = *(const __attribute__((address_space(1))) v4f*)(pa + ko);
+                a1 = *(const __attribute__((address_space(1))) v4f*)(pa + ko + 4);
+                b0 = *(const __attribute__((address_space(1))) v4u*)(pb + (it & 63) * 3072);
+                b1 = *(const __attribute__((address_space(1))) v4u*)(pb + (it & 63) * 3072 + 1024);
+                b2 = *(const __attribute__((address_space(1))) v4u*)(pb + (it & 63) * 3072 + 2048);
+            }
+            if (MODE == 5) {                                   // pin the interleave: 1 MFMA : 2 VALU
+#pragma unroll
+                for (int r = 0; r < 24; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x2, 2, 0);
+                }
             }
             __syncthreads();
             cur ^= 1;
@@ -200,8 +224,12 @@ int main()
     const double s2 = run<2, 2>("bf16x3 + reads + split VALU (8 fp32 / thread) + 6 ds_write_b128 + barrier");
     run<3, 1>("bf16x3 + reads + split + writes + global loads (A fp32, B pre-split)");
     const double s3 = run<3, 2>("bf16x3 + reads + split + writes + global loads (A fp32, B pre-split)");
+    run<4, 1>("bf16x3 pipelined: split interleaved with the MFMAs, loads 2 k-steps ahead");
+    const double s4 = run<4, 2>("bf16x3 pipelined: split interleaved with the MFMAs, loads 2 k-steps ahead");
+    run<5, 1>("bf16x3 pipelined + sched_group_barrier (1 MFMA : 2 VALU)");
+    run<5, 2>("bf16x3 pipelined + sched_group_barrier (1 MFMA : 2 VALU)");
     runf32<1>();
     const double f = runf32<2>();
-    printf("ratio: staged bf16x3 loop / f32 MFMA loop = %.2f (LDS-staged), %.2f (with global loads)   [kill criterion: < 1.3]\n", s2 / f, s3 / f);
+    printf("ratio: staged bf16x3 loop / f32 MFMA loop = %.2f (LDS-staged), %.2f (with global loads), %.2f (pipelined)   [kill criterion: < 1.3]\n", s2 / f, s3 / f, s4 / f);
     return 0;
 }
