@@ -202,16 +202,27 @@ def split_bf16_weight(wp, ldw):
     return wb
 
 
-def split_bf16_tile(M, ldw, nsub=1, ksplit=1):
-    """N tile of the split-bf16 kernel for a launch with M output pixels per sub-convolution: 128 when the 128 x 128 tiling still gives
-    every CU a block, else 64; None when ldw is not a multiple of 64 (the launch stays on the f32 kernel)."""
+def split_bf16_tile(M, ldw, nsub=1, ksplit=1, force=False):
+    """N tile of the split-bf16 kernel for a launch with M output pixels per sub-convolution, or None = the launch stays on the f32
+    kernel.  The first version of the kernel only has 128-row tiles: it measured 1.05-1.5x the f32 kernel wherever that tiling gives
+    every CU two blocks and 0.62-0.82x where it does not (profiles/r5_bf16x3_ab_v1.txt), so the rule is: 128 x 128 when it makes
+    >= MINBLOCKS blocks, else 128 x 64 when that does, else f32; split-K launches (small M by construction) stay on the f32 kernel.
+    CP_SPLIT_BF16_TILE forces an N tile (tests, A/B), CP_SPLIT_BF16_MINBLOCKS the floor (default 512; 0 = every eligible launch).
+    `force` (a launch built with split_bf16=True): no floor, split-K allowed."""
     if ldw % 64:
         return None
-    blocks = ((M + 127) // 128) * max(1, nsub) * max(1, ksplit)
     forced = os.environ.get("CP_SPLIT_BF16_TILE")
     if forced:
         return int(forced) if ldw % int(forced) == 0 else 64
-    return 128 if ldw % 128 == 0 and blocks * (ldw // 128) >= 256 else 64
+    floor = 0 if force else int(os.environ.get("CP_SPLIT_BF16_MINBLOCKS", "512"))
+    if floor == 0:
+        return 128 if ldw % 128 == 0 and ((M + 127) // 128) * max(1, nsub) * max(1, ksplit) * (ldw // 128) >= 256 else 64
+    if ksplit > 1:
+        return None
+    mt = ((M + 127) // 128) * max(1, nsub)
+    if ldw % 128 == 0 and mt * (ldw // 128) >= floor:
+        return 128
+    return 64 if mt * (ldw // 64) >= floor else None
 
 
 def conv2d(srcs, wp, scale, shift, out, **kw):
@@ -277,7 +288,7 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
         assert len(srcs) == 1 and not in_nchw
         return Launch("cp_conv3x3_winograd_f32", d, [srcs[0], wino, scale, shift, res, out])
     if (SPLIT_BF16 if split_bf16 is None else split_bf16) and tile == 0 and not in_nchw:
-        bn = split_bf16_tile(B * Ho * Wo, d.ldw, nsub, ksplit)
+        bn = split_bf16_tile(B * Ho * Wo, d.ldw, nsub, ksplit, force=split_bf16 is True)
         c16 = kh == 3 and kw == 3 and len(srcs) == 1 and srcs[0].shape[3] == 16 and cout <= 32      # stays on conv3x3_c16_kernel
         if bn is not None and not c16 and all(s.data_ptr() % 16 == 0 for s in srcs):
             d.tile = SPLIT_BF16_TILE[bn]

@@ -159,6 +159,51 @@ def test_conv_split_bf16_concat_deconv_splitk_nchw():
     _close(out, ref, 1e-5)
 
 
+def test_conv2d_group_equals_single_launches():
+    """cp_conv2d_group_f32 (HRNet's fuse layers as ONE launch, pose_higher_hrnet.py:169-212): eight independent convs of mixed kind --
+    1x1 and stride-2 3x3, 16..256 input channels, 32..256 outputs (padded to the shared 64-wide tile), ragged maps, ReLU or not --
+    must give the SAME BITS as the eight single launches of the 64 x 64 tile, and agree with torch-CPU."""
+    from centerpose_amd import _lib, ops
+    g = torch.Generator().manual_seed(11)
+    B = 2
+    cases = [(32, 64, 3, 2, 1, (24, 20), True), (64, 32, 1, 1, 0, (12, 10), False), (128, 32, 1, 1, 0, (6, 5), False), (256, 64, 1, 1, 0, (3, 3), False),
+             (32, 32, 3, 2, 1, (24, 20), True), (64, 128, 3, 2, 1, (12, 10), False), (128, 256, 3, 2, 1, (7, 5), False), (16, 48, 1, 1, 0, (9, 11), True)]
+    recs, refs, singles = [], [], []
+    sizes = []
+    for cin, cout, k, st, pd, (H, W), relu in cases:
+        Ho, Wo = (H + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+        sizes.append(B * Ho * Wo * ops.round_up(cout, 16))
+    whole = torch.full((sum(sizes),), float("nan"), device="cuda")
+    off = 0
+    for (cin, cout, k, st, pd, (H, W), relu), n in zip(cases, sizes):
+        x = torch.randn(B, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+        bn = _rand_bn(g, cout)
+        ref = _ref_bn(F.conv2d(x, w, None, st, pd), bn)
+        refs.append(F.relu(ref) if relu else ref)
+        Ho, Wo = ref.shape[2:]
+        cp = ops.round_up(cout, 16)
+        wp = ops.pack_conv_weight(w.cuda())
+        sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+        ldw = ops.round_up(wp.shape[0], 64)
+        wp, sc, sh = ops.pad_rows(wp, ldw), ops.pad_vec(sc, ldw), ops.pad_vec(sh, ldw)
+        out = whole[off:off + n].view(B, Ho, Wo, cp)
+        off += n
+        recs.append(dict(x=_nhwc(x), wp=wp, scale=sc, shift=sh, out=out, cout=cp, k=k, stride=st, pad=pd, act=ops.ACT_RELU if relu else ops.ACT_NONE))
+        one = torch.full((B, Ho, Wo, cp), float("nan"), device="cuda")
+        ops.conv2d([recs[-1]["x"]], wp, sc, sh, one, kh=k, kw=k, stride=st, pad=pd, cout=cp, act=recs[-1]["act"], tile=64064, split_bf16=False)
+        singles.append(one)
+    la = ops.conv2d_group_launch(recs, whole)
+    la.run()
+    assert la.kernel == "igemm_conv_group_kernel"
+    for r, one, ref, (cin, cout, *_rest) in zip(recs, singles, refs, cases):
+        assert torch.equal(r["out"], one), "%d->%d: grouped launch differs from the single launch" % (cin, cout)
+        assert (r["out"][..., cout:] == 0).all()                                  # padding channels are written as exact zeros
+        _close(r["out"][..., :cout].permute(0, 3, 1, 2), ref)
+    with pytest.raises(Exception):
+        ops.conv2d_group_launch(recs + recs[:1], whole)                            # nine members
+
+
 def test_conv_concat_sources_and_channel_views():
     """Root: cat -> 1x1 conv (pose_dla_dcn.py:155-163) without materialising the cat; sources may be
     channel slices of wider tensors (pixel stride > C)."""
