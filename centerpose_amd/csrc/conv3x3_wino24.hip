@@ -30,7 +30,10 @@
 #define W24_PWP 20                                 // patch row pitch in float4 slots
 #define W24_KS 16
 #define W24_CGS (W24_KS / 4)
-#define W24_CG (W24_PH * W24_PWP * 4)              // floats per 4-channel plane
+#define W24_CG (W24_PH * W24_PWP * 4 + 16)         // floats per 4-channel plane: 1440 + 16 -- with 1440 (= 32 mod 64 banks) the four channel
+                                                   // quads q = 0..3 that one 8-lane ds_write_b128 group stores for a patch pixel landed on banks
+                                                   // {0, 32, 0, 32}: a 2-way conflict on EVERY patch store (SQ_LDS_BANK_CONFLICT 43 % of the LDS-active
+                                                   // cycles, profiles/r4_pmc_wino_kernels.txt); 1456 puts them on {0, 48, 32, 16}.  Reads stay inside one plane
 #define W24_STAGE (W24_CGS * W24_CG)               // floats per stage buffer (23 KB)
 #define W24_F4 (W24_PH * W24_PW * W24_CGS)         // 1296 float4 per stage
 #define W24_SLOTS ((W24_F4 + IG_THREADS - 1) / IG_THREADS)
@@ -229,7 +232,7 @@ __device__ __forceinline__ void w24_block(const ConvArgs& a, const W24Grid& gd, 
         const bool inl = idx < W24_F4;
         ok[s] = inl && gy >= 0 && gy < a.H && gx >= 0 && gx < a.W;
         go[s] = ok[s] ? ((b * a.H + gy) * a.W + gx) * ld + q * 4 : 0;
-        lo[s] = inl ? ((q * W24_PH + py) * W24_PWP + (px ^ ((py >> 1) & 3))) * 4 : -1;
+        lo[s] = inl ? q * W24_CG + (py * W24_PWP + (px ^ ((py >> 1) & 3))) * 4 : -1;
     }
     float4 rg[W24_SLOTS];
     auto stage_load = [&](int c0) __attribute__((always_inline)) {

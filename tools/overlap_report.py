@@ -12,7 +12,13 @@ for i, (n, s, e) in enumerate(ev):
 pts.sort()
 active, alone, shared = set(), collections.Counter(), collections.Counter()
 last = None
+idle, ngaps, two = 0, 0, 0
 for t, kind, i in pts:
+    if last is not None and not active and t - last < 200000:      # < 0.2 ms with nothing running: a gap inside a step (launch latency), not the host between steps
+        idle += t - last
+        ngaps += 1
+    if last is not None and len(active) >= 2:
+        two += t - last
     if last is not None and active:
         dt = t - last
         if len(active) == 1:
@@ -25,7 +31,9 @@ for t, kind, i in pts:
     last = t
 short = lambda n: n.replace("void ", "").split("(")[0][:60]
 tot_alone = sum(alone.values())
-print("%d steps; GPU time with exactly one kernel running: %.3f ms per step" % (steps, tot_alone / steps / 1e6))
+print("%d steps; GPU time with exactly one kernel running: %.3f ms per step; two or more: %.3f ms; NO kernel running inside a step (gaps < 0.2 ms): "
+      "%.3f ms per step in %.1f gaps (%.2f us each)" % (steps, tot_alone / steps / 1e6, two / steps / 1e6, idle / steps / 1e6, ngaps / steps,
+                                                       idle / max(1, ngaps) / 1e3))
 for n in sorted(set(alone) | set(shared), key=lambda n: -alone[n]):
     if (alone[n] + shared[n]) / steps < 5000: continue
     print("  %-60s alone %7.3f ms  shared %7.3f ms per step" % (short(n), alone[n] / steps / 1e6, shared[n] / steps / 1e6))
