@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-other-configs", action="store_true", help="skip the res_50 B=8 / hrnet B=8 evidence runs after the timed region")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)      # internal: one worker of cpu_baseline's multi-process layouts
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="steps in flight: D instances of the compiled plan (own activations + captured graph) replayed round-robin on D "
+                         "streams, so the next step's kernels fill the launch gaps / tails of the current one (1 = one replay after the other)")
     ap.add_argument("--force-gather", action="store_true",
                     help="N = 1: create a process group of ONE rank (RCCL on the GPU box) and run the step's all-gather through it on "
                          "the side stream exactly as at N > 1 -- everything of the multi-GPU path except the xGMI wire")
@@ -304,15 +307,47 @@ def roofline(eng, arch, B, wall_ms=None):
     return roof
 
 
-def make_engine(arch="dla_34", B=16, dev="cuda", use_graph=True):
+def make_engine(arch="dla_34", B=16, dev="cuda", use_graph=True, const_cache=None, sched_cache=None):
     """THE timed configuration: seeded synthetic checkpoint, B x 3 x 512 x 512, the decode inside the engine's schedule
     (forward + sigmoid + decode = ONE two-stream hipGraph replay per step).  tests/test_engine_hip.py::
     test_timed_configuration_parity builds its engine through this function, so what is parity-tested is what is timed."""
     from centerpose_amd import engine, synth
-    return engine.Engine(arch, synth.make_state_dict(arch), B, 512, 512, device=dev, use_graph=use_graph, decode_k=100)
+    return engine.Engine(arch, synth.make_state_dict(arch), B, 512, 512, device=dev, use_graph=use_graph, decode_k=100,
+                         const_cache=const_cache, sched_cache=sched_cache)
 
 
-def other_configs(dev, steps=20, warmup=5):
+def make_engines(arch, B, dev, depth, use_graph=True):
+    """`depth` instances of THE timed configuration (engine.EnginePipeline's arrangement: own activations and captured graph each,
+    packed constants and schedule shared) + one stream per instance; depth 1 = the single engine on the current stream."""
+    import torch
+    cc, sc = {}, {}
+    engs = [make_engine(arch, B, dev, use_graph, cc, sc) for _ in range(max(1, depth))]
+    streams = [torch.cuda.Stream(device=dev) for _ in engs] if depth > 1 else [None]
+    return engs, streams
+
+
+def timed_replays(engs, streams, steps, warmup):
+    """`steps` replays round-robin over the instances (instance i % D on stream i % D), host clock around one device synchronisation."""
+    import contextlib
+    import torch
+    def one(i):
+        e, st = engs[i % len(engs)], streams[i % len(engs)]
+        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            e.process(e.input)
+    for st in streams:
+        if st is not None:
+            st.wait_stream(torch.cuda.current_stream())
+    for i in range(warmup):
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        one(i)
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def other_configs(dev, steps=20, warmup=5, depth=2):
     """BASELINE.json configs[1] (res_50 512x512 B=8) and the per-GPU shape of configs[4] (hrnet_w32 512x512 B=8) through the same
     engine / kernels, AFTER the timed region of the metric's own workload: `steps` graph replays each, timed like the main loop
     (host clock around synchronised replays), plus the in-sequence per-kernel accounting.  Not the metric -- driver-visible
@@ -326,20 +361,15 @@ def other_configs(dev, steps=20, warmup=5):
         saved = ops.SPLIT_BF16
         try:
             ops.SPLIT_BF16 = split
-            eng = make_engine(arch, B, dev)
+            engs, streams = make_engines(arch, B, dev, depth)
             ops.SPLIT_BF16 = saved
-            x = eng.input
-            for _ in range(warmup):
-                eng.process(x)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(steps):
-                eng.process(x)
-            torch.cuda.synchronize()
-            el = time.perf_counter() - t0
-            r = roofline(eng, arch, B, wall_ms=el / steps * 1e3)
+            eng = engs[0]
+            el1 = timed_replays(engs[:1], [None], steps, warmup)            # one replay after the other (rounds 1-4)
+            el = timed_replays(engs, streams, steps, warmup) if depth > 1 else el1
+            r = roofline(eng, arch, B, wall_ms=el1 / steps * 1e3)
             out[key] = {
-                "images_per_sec": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps,
+                "images_per_sec": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "steps_in_flight": depth,
+                "one_step_in_flight": {"images_per_sec": round(B * steps / el1, 1), "ms_per_step": round(el1 / steps * 1e3, 3)},
                 "graph_capture": eng.capture_mode, "end_to_end_tflops": round(eng.flops_per_image * B * steps / el / 1e12, 2),
                 "all_mfma_executed_frac": r["all_mfma_kernels"]["executed_frac"],
                 "min_bound_frac": r["min_bound_frac"],
@@ -347,7 +377,7 @@ def other_configs(dev, steps=20, warmup=5):
                 "templates": r["templates"]}
             if split:
                 out[key]["mode"] = "CP_SPLIT_BF16=1 (opt-in, fp32-equivalent 3-term bf16 split on v_mfma_f32_32x32x16_bf16; NOT the metric's arithmetic path)"
-            del eng
+            del eng, engs
             torch.cuda.empty_cache()
         except Exception as e:            # evidence, not the metric: a failure here must not take the bench line down
             out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
@@ -380,20 +410,36 @@ def main():
     B = args.batch
     # the decode is part of the engine's schedule (decode_k): forward + sigmoid + decode = ONE hipGraph replay per step, the
     # peak extraction overlapping the last head convolutions on the second capture stream
-    eng = make_engine(args.arch, B, dev, use_graph=not args.no_graph)
+    # Round 5: D = --in-flight instances of that plan (default 2), replayed round-robin on D streams -- step i + 1 starts while step i
+    # is still running, its kernels fill the launch gaps and the tails of the chain (engine.EnginePipeline; every step still is one
+    # batch of B images through the whole path, and all of the K timed steps complete inside the timed region).  D = 1: rounds 1-4.
+    D = max(1, args.in_flight)
+    engs, streams = make_engines(args.arch, B, dev, D, use_graph=not args.no_graph)
+    eng = engs[0]
     lo, _ = cpd.shard_range(B * world, rank, world)
     images = synth.make_images(B, seed=317 + lo).to(dev)      # this rank's shard, resident in HBM
-    eng.input.copy_(images)
+    for e in engs:
+        e.input.copy_(images)
     gat = cpd.DetsGatherer(global_batch=B * world, time_waits=True, force=args.force_gather)
+    import contextlib
+    nstep = [0]
 
-    def step():
-        """one batch through backbone + heads + decode; the all-gather of its detections is left running on the side
-        stream and collected one step later (the first call returns None)."""
-        _, dets = eng.process(eng.input)
-        prev = gat.collect() if gat.pending else None
-        gat.submit(dets.clone())         # eng.dets is a static buffer: the exchange / the caller get their own copy
+    def step(mark=None):
+        """one batch through backbone + heads + decode on the next plan instance (and its stream); the all-gather of its
+        detections is left running on the side stream and collected one step later (the first call returns None)."""
+        e, st = engs[nstep[0] % D], streams[nstep[0] % D]
+        nstep[0] += 1
+        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+            _, dets = e.process(e.input)
+            prev = gat.collect() if gat.pending else None
+            gat.submit(dets.clone())         # e.dets is a static buffer: the exchange / the caller get their own copy
+            if mark is not None:
+                mark.record()
         return prev
 
+    for st in streams:
+        if st is not None:
+            st.wait_stream(torch.cuda.current_stream())
     for _ in range(args.warmup):
         step()
     if gat.pending:
@@ -406,8 +452,7 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
-        step()
-        marks[i + 1].record()
+        step(marks[i + 1])
     out = gat.collect()                              # the last step's gather is inside the timed region
     torch.cuda.synchronize()
     if grouped:
@@ -450,29 +495,35 @@ def main():
                 "config": {"workload": "%s 512x512 batch=%d per GPU: HIP conv/DCNv2 backbone + heads + HIP heatmap "
                                        "decode%s" % (args.arch, B, ", RCCL all-gather of decoded poses (side stream)" if world > 1 else ""),
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
-                           "weights": "seeded synthetic checkpoint (reference key layout)"},
+                           "weights": "seeded synthetic checkpoint (reference key layout)",
+                           "steps_in_flight": D,
+                           "pipeline": ("%d instances of the compiled plan (own activations + captured two-stream hipGraph each, packed "
+                                        "weights shared), replayed round-robin on %d streams: step i+1 starts while step i is running; every "
+                                        "step is one batch of %d images through the whole path; `one_step_in_flight` = one replay after the "
+                                        "other, as timed in rounds 1-4" % (D, D, B)) if D > 1 else "one replay after the other"},
                 "ranks": dist.get_world_size() if grouped else 1,
                 "backend": dist.get_backend() if grouped else None,
                 "rank_ms_per_step": {k: round(v, 3) for k, v in rank_ms.items()},
                 "gather": gather_info,
                 "graph_capture": eng.capture_mode if not args.no_graph else "eager",
                 "step_ms": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3),
-                            "min": round(per[0], 3), "max": round(per[-1], 3), "source": "HIP events per step on the launch stream"},
+                            "min": round(per[0], 3), "max": round(per[-1], 3),
+                            "source": "HIP events per step on the launch stream" if D == 1 else
+                                      "time between the completions of consecutive steps (HIP events at the end of each step, on its instance's stream)"},
                 "end_to_end_tflops": round(eng.flops_per_image * value / world / 1e12, 2),
                 "activation_mb": round(eng.activation_bytes / 1e6, 1)}
         if not args.no_profile:
             line["roofline"] = roofline(eng, args.arch, B, wall_ms=ms_step)
             # DVFS (MI355X_MICROARCH.md: short bursts clock higher): the same step over >= 1000 replays AFTER the timed region
             n_sus = max(1000, args.steps)
-            torch.cuda.synchronize()
-            ts = time.perf_counter()
-            for _ in range(n_sus):
-                eng.process(eng.input)
-            torch.cuda.synchronize()
-            sus = time.perf_counter() - ts
+            sus = timed_replays(engs, streams, n_sus, 0)
             line["sustained"] = {"replays": n_sus, "seconds": round(sus, 3), "images_per_sec": round(B * n_sus / sus, 1),
-                                 "ms_per_step": round(sus / n_sus * 1e3, 3),
-                                 "note": "graph replays back to back after the timed region, one host sync at the end (no gather, no clone)"}
+                                 "ms_per_step": round(sus / n_sus * 1e3, 3), "steps_in_flight": D,
+                                 "note": "graph replays after the timed region, one host sync at the end (no gather, no clone)"}
+            # what rounds 1-4 timed: ONE instance, one replay after the other on the current stream (same kernels, same bits)
+            n_one = max(100, args.steps)
+            one = timed_replays(engs[:1], [None], n_one, 3)
+            line["one_step_in_flight"] = {"replays": n_one, "images_per_sec": round(B * n_one / one, 1), "ms_per_step": round(one / n_one * 1e3, 3)}
             # ---- decode alone (latency-bound; reported as us/batch next to its HBM GB/s) ------------------
             hm, wh, hps, reg, hm_hp, hp_offset = eng.outputs
             for _ in range(3):
@@ -488,7 +539,7 @@ def main():
             line["decode"] = {"us_per_batch": round(dec_us, 1), "algorithmic_bytes": dec_bytes,
                               "gbps": round(dec_bytes / dec_us / 1e3, 1), "kernels": "nms_topk_kernel + pose_assign_kernel"}
         if world == 1 and not args.no_profile and not args.no_other_configs and args.arch == "dla_34":
-            line["other_configs"] = other_configs(dev)
+            line["other_configs"] = other_configs(dev, depth=D)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch)
         print(json.dumps(line), flush=True)

@@ -853,3 +853,49 @@ class Engine:
             sm.sort()
             recs.append(dict(kind=kind, name=name, fn=launch.fn, kernel=launch.kernel, flops=flops, bytes=nb, ms=sm[len(sm) // 2]))
         return recs
+
+
+class EnginePipeline:
+    """`depth` instances of ONE compiled network, replayed round-robin, each on its own HIP stream: `depth` steps in flight.
+
+    Why: a step is a dependency chain of ~100 kernel launches.  rocprofv3 (profiles/r5_two_stream_overlap.txt) shows, per 7.3 ms step of
+    dla_34 B=16, 0.85 ms with NO kernel running (92 gaps between dependent graph nodes), 4.3 ms with exactly one (tails of one launch
+    cannot be filled by the next, which depends on it) and only 3.4 ms with the two capture streams both busy; hrnet / res_50 at B=8
+    under-fill the chip in most launches.  A second, independent step has no dependency on the first: its kernels fill those holes.
+    Same kernels, same bits (every instance owns its activations, static input / output buffers and captured two-stream hipGraph;
+    the packed constants and the launch schedule are shared through `const_cache` / `sched_cache`); what changes is batch LATENCY
+    (~depth x) against THROUGHPUT (measured: dla_34 B=16 +3 %, res_50 B=8 +12 %, hrnet B=8 +26 %).  The reference runs one image at
+    a time, synchronously (lib/detectors/base_detector.py:79-140); this is the serving-side overlap it leaves on the table.
+
+    `process(images=None)` enqueues one step on the next instance's stream and returns `(outputs, dets, stream)`: static buffers of
+    that instance, valid once `stream` has been waited for (`torch.cuda.current_stream().wait_stream(stream)` or a device
+    synchronisation) and until the instance's next turn (`depth` calls later)."""
+
+    def __init__(self, arch, state_dict, batch, height=512, width=512, device="cuda", depth=2, **kw):
+        if depth < 1:
+            raise ValueError("depth >= 1")
+        cc = kw.pop("const_cache", None)
+        sc = kw.pop("sched_cache", None)
+        cc = {} if cc is None else cc
+        sc = {} if sc is None else sc
+        self.engines = [Engine(arch, state_dict, batch, height, width, device, const_cache=cc, sched_cache=sc, **kw) for _ in range(depth)]
+        dev = self.engines[0].device
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
+        self.depth, self.turn = depth, 0
+
+    def next_slot(self):
+        """(engine, stream) of the next step; advances the round-robin."""
+        i = self.turn % self.depth
+        self.turn += 1
+        return self.engines[i], self.streams[i]
+
+    def process(self, images=None):
+        eng, s = self.next_slot()
+        s.wait_stream(torch.cuda.current_stream(eng.device))      # the caller's writes to `images` (and the previous owner of this slot)
+        with torch.cuda.stream(s):
+            outs, dets = eng.process(eng.input if images is None else images)
+        return outs, dets, s
+
+    def synchronize(self):
+        for s in self.streams:
+            s.synchronize()

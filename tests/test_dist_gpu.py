@@ -177,6 +177,10 @@ def test_bench_single_gpu_line_contract():
     assert 0.3 < mb["of_in_sequence"] <= 1.0 and 0.3 < mb["of_wall_step"] <= 1.05 and mb["bound_ms_per_step"] < line["ms_per_step"]
     assert all(0.0 < t["min_bound_frac"] <= 1.05 for t in roof["templates"].values())
     assert any("traffic_ratio" in t for t in roof["templates"].values())
+    # round 5: two steps in flight by default (engine.EnginePipeline's arrangement); the one-replay-after-the-other figure of rounds
+    # 1-4 rides along and cannot be faster than the pipelined one by more than noise
+    assert line["config"]["steps_in_flight"] == 2 and "instances of the compiled plan" in line["config"]["pipeline"]
+    assert 0.7 * line["value"] < line["one_step_in_flight"]["images_per_sec"] < 1.03 * line["value"]
     sus = line["sustained"]
     assert sus["replays"] >= 1000 and 0.8 * line["value"] < sus["images_per_sec"] < 1.2 * line["value"]
     # the kernels this line timed, for tests/test_engine_hip.py::test_timed_configuration_parity of the SAME pytest session (it runs
