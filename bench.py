@@ -48,8 +48,8 @@ def parse_args():
     ap.add_argument("--no-other-configs", action="store_true", help="skip the res_50 B=8 / hrnet B=8 evidence runs after the timed region")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)      # internal: one worker of cpu_baseline's multi-process layouts
     ap.add_argument("--in-flight", type=int, default=2,
-                    help="steps in flight: D instances of the compiled plan (own activations + captured graph) replayed round-robin on D "
-                         "streams, so the next step's kernels fill the launch gaps / tails of the current one (1 = one replay after the other)")
+                    help="steps in flight: D instances of the compiled plan (own activations) scheduled together and captured into ONE "
+                         "hipGraph, so one step's kernels fill the launch gaps / chain tails of the other (1 = one step per replay)")
     ap.add_argument("--force-gather", action="store_true",
                     help="N = 1: create a process group of ONE rank (RCCL on the GPU box) and run the step's all-gather through it on "
                          "the side stream exactly as at N > 1 -- everything of the multi-GPU path except the xGMI wire")
@@ -317,32 +317,33 @@ def make_engine(arch="dla_34", B=16, dev="cuda", use_graph=True, const_cache=Non
 
 
 def make_engines(arch, B, dev, depth, use_graph=True):
-    """`depth` instances of THE timed configuration (engine.EnginePipeline's arrangement: own activations and captured graph each,
-    packed constants and schedule shared) + one stream per instance; depth 1 = the single engine on the current stream."""
-    import torch
-    cc, sc = {}, {}
-    engs = [make_engine(arch, B, dev, use_graph, cc, sc) for _ in range(max(1, depth))]
-    streams = [torch.cuda.Stream(device=dev) for _ in engs] if depth > 1 else [None]
-    return engs, streams
+    """`depth` instances of THE timed configuration (own activations / static buffers each, packed constants shared) and, for
+    depth > 1, the engine.EnginePipeline that schedules their launch lists together and captures ONE hipGraph: one replay = `depth`
+    steps in flight.  -> (engines, pipeline or None)"""
+    from centerpose_amd import engine
+    cc = {}
+    engs = [make_engine(arch, B, dev, use_graph, cc, None) for _ in range(max(1, depth))]
+    pipe = engine.EnginePipeline(None, None, B, engines=engs) if depth > 1 and use_graph else None
+    return engs, pipe
 
 
-def timed_replays(engs, streams, steps, warmup):
-    """`steps` replays round-robin over the instances (instance i % D on stream i % D), host clock around one device synchronisation."""
-    import contextlib
+def timed_replays(eng, pipe, steps, warmup):
+    """`steps` steps: with a pipeline, steps // depth joint replays (depth steps each) + the remainder as single replays of `eng`;
+    host clock around one device synchronisation.  -> seconds"""
     import torch
-    def one(i):
-        e, st = engs[i % len(engs)], streams[i % len(engs)]
-        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-            e.process(e.input)
-    for st in streams:
-        if st is not None:
-            st.wait_stream(torch.cuda.current_stream())
-    for i in range(warmup):
-        one(i)
+    D = pipe.depth if pipe is not None else 1
+    def run(n):
+        for _ in range(n // D if pipe is not None else 0):
+            pipe.process_all()
+        for _ in range(n % D if pipe is not None else n):
+            eng.process(eng.input)
+    eng.process(eng.input)                                   # (captures happen outside the timing)
+    if pipe is not None:
+        pipe.process_all()
+    run(warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(steps):
-        one(i)
+    run(steps)
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
@@ -361,23 +362,23 @@ def other_configs(dev, steps=20, warmup=5, depth=2):
         saved = ops.SPLIT_BF16
         try:
             ops.SPLIT_BF16 = split
-            engs, streams = make_engines(arch, B, dev, depth)
+            engs, pipe = make_engines(arch, B, dev, depth)
             ops.SPLIT_BF16 = saved
             eng = engs[0]
-            el1 = timed_replays(engs[:1], [None], steps, warmup)            # one replay after the other (rounds 1-4)
-            el = timed_replays(engs, streams, steps, warmup) if depth > 1 else el1
+            el1 = timed_replays(eng, None, steps, warmup)                     # one replay after the other (rounds 1-4)
+            el = timed_replays(eng, pipe, steps, warmup) if pipe is not None else el1
             r = roofline(eng, arch, B, wall_ms=el1 / steps * 1e3)
             out[key] = {
                 "images_per_sec": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "steps_in_flight": depth,
                 "one_step_in_flight": {"images_per_sec": round(B * steps / el1, 1), "ms_per_step": round(el1 / steps * 1e3, 3)},
-                "graph_capture": eng.capture_mode, "end_to_end_tflops": round(eng.flops_per_image * B * steps / el / 1e12, 2),
+                "graph_capture": eng.capture_mode, "pipeline_graph_capture": pipe.capture_mode if pipe is not None else None, "end_to_end_tflops": round(eng.flops_per_image * B * steps / el / 1e12, 2),
                 "all_mfma_executed_frac": r["all_mfma_kernels"]["executed_frac"],
                 "min_bound_frac": r["min_bound_frac"],
                 "dominant_kernel": r["kernel"], "dominant_frac": r["frac"], "dominant_time_share": r["time_share"],
                 "templates": r["templates"]}
             if split:
                 out[key]["mode"] = "CP_SPLIT_BF16=1 (opt-in, fp32-equivalent 3-term bf16 split on v_mfma_f32_32x32x16_bf16; NOT the metric's arithmetic path)"
-            del eng, engs
+            del eng, engs, pipe
             torch.cuda.empty_cache()
         except Exception as e:            # evidence, not the metric: a failure here must not take the bench line down
             out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
@@ -410,49 +411,57 @@ def main():
     B = args.batch
     # the decode is part of the engine's schedule (decode_k): forward + sigmoid + decode = ONE hipGraph replay per step, the
     # peak extraction overlapping the last head convolutions on the second capture stream
-    # Round 5: D = --in-flight instances of that plan (default 2), replayed round-robin on D streams -- step i + 1 starts while step i
-    # is still running, its kernels fill the launch gaps and the tails of the chain (engine.EnginePipeline; every step still is one
-    # batch of B images through the whole path, and all of the K timed steps complete inside the timed region).  D = 1: rounds 1-4.
-    D = max(1, args.in_flight)
-    engs, streams = make_engines(args.arch, B, dev, D, use_graph=not args.no_graph)
-    eng = engs[0]
+    # Round 5: D = --in-flight instances of that plan (default 2), their launch lists scheduled TOGETHER on the two capture streams and
+    # captured into ONE hipGraph (engine.EnginePipeline): one replay = D steps in flight, the kernels of one step fill the launch gaps
+    # and the tails of the other's dependency chain.  Every step still is one batch of B images through the whole path, and all of the
+    # K timed steps complete inside the timed region (K // D joint replays + K % D single replays).  D = 1: rounds 1-4.
+    D = max(1, args.in_flight) if not args.no_graph else 1
     lo, _ = cpd.shard_range(B * world, rank, world)
     images = synth.make_images(B, seed=317 + lo).to(dev)      # this rank's shard, resident in HBM
+    engs, pipe = make_engines(args.arch, B, dev, D, use_graph=not args.no_graph)
+    eng = engs[0]
     for e in engs:
         e.input.copy_(images)
     gat = cpd.DetsGatherer(global_batch=B * world, time_waits=True, force=args.force_gather)
-    import contextlib
-    nstep = [0]
 
-    def step(mark=None):
-        """one batch through backbone + heads + decode on the next plan instance (and its stream); the all-gather of its
-        detections is left running on the side stream and collected one step later (the first call returns None)."""
-        e, st = engs[nstep[0] % D], streams[nstep[0] % D]
-        nstep[0] += 1
-        with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
-            _, dets = e.process(e.input)
-            prev = gat.collect() if gat.pending else None
-            gat.submit(dets.clone())         # e.dets is a static buffer: the exchange / the caller get their own copy
-            if mark is not None:
-                mark.record()
+    def hand_over(dets):
+        """the step's detections: the all-gather is left running on the side stream and collected one step later"""
+        prev = gat.collect() if gat.pending else None
+        gat.submit(dets.clone())         # static buffer of the plan instance: the exchange / the caller get their own copy
         return prev
 
-    for st in streams:
-        if st is not None:
-            st.wait_stream(torch.cuda.current_stream())
-    for _ in range(args.warmup):
-        step()
+    def run_steps(n, marks=None):
+        """n steps: n // D joint replays (D steps each) + n % D single replays; one HIP event after every replay."""
+        done = 0
+        for _ in range(n // D if pipe is not None else 0):
+            for _, dets in pipe.process_all():
+                hand_over(dets)
+            done += D
+            if marks is not None:
+                marks.append((torch.cuda.Event(enable_timing=True), D))
+                marks[-1][0].record()
+        for _ in range(n - done):
+            _, dets = eng.process(eng.input)
+            hand_over(dets)
+            if marks is not None:
+                marks.append((torch.cuda.Event(enable_timing=True), 1))
+                marks[-1][0].record()
+
+    eng.process(eng.input)               # captures (and the measured schedules) outside the timing
+    if pipe is not None:
+        pipe.process_all()
+    run_steps(args.warmup)
     if gat.pending:
         gat.collect()
     torch.cuda.synchronize()
     if grouped:
         dist.barrier()
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks = []
+    start = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    marks[0].record()
-    for i in range(args.steps):
-        step(marks[i + 1])
+    start.record()
+    run_steps(args.steps, marks)
     out = gat.collect()                              # the last step's gather is inside the timed region
     torch.cuda.synchronize()
     if grouped:
@@ -486,7 +495,11 @@ def main():
     if rank == 0:
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
-        per = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+        per, last = [], start
+        for ev, nst in marks:                              # a joint replay completes D steps at once: its time is shared by them
+            per += [last.elapsed_time(ev) / nst] * nst
+            last = ev
+        per.sort()
         pct = lambda q: per[min(len(per) - 1, int(q * len(per)))]
         line = {"metric": "images/sec end-to-end (backbone+decode), DLA-34 512x512", "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -497,32 +510,34 @@ def main():
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
                            "weights": "seeded synthetic checkpoint (reference key layout)",
                            "steps_in_flight": D,
-                           "pipeline": ("%d instances of the compiled plan (own activations + captured two-stream hipGraph each, packed "
-                                        "weights shared), replayed round-robin on %d streams: step i+1 starts while step i is running; every "
-                                        "step is one batch of %d images through the whole path; `one_step_in_flight` = one replay after the "
-                                        "other, as timed in rounds 1-4" % (D, D, B)) if D > 1 else "one replay after the other"},
+                           "pipeline": ("%d instances of the compiled plan (own activations and static buffers, packed weights shared) whose "
+                                        "launch lists are scheduled together on the two capture streams and captured into ONE hipGraph: one "
+                                        "replay = %d steps (each one batch of %d images through the whole path) whose kernels fill each "
+                                        "other's launch gaps and chain tails; `one_step_in_flight` = one step per replay, as timed in rounds "
+                                        "1-4" % (D, D, B)) if D > 1 else "one step per replay"},
                 "ranks": dist.get_world_size() if grouped else 1,
                 "backend": dist.get_backend() if grouped else None,
                 "rank_ms_per_step": {k: round(v, 3) for k, v in rank_ms.items()},
                 "gather": gather_info,
                 "graph_capture": eng.capture_mode if not args.no_graph else "eager",
+                "pipeline_graph_capture": pipe.capture_mode if pipe is not None else None,
                 "step_ms": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3),
                             "min": round(per[0], 3), "max": round(per[-1], 3),
                             "source": "HIP events per step on the launch stream" if D == 1 else
-                                      "time between the completions of consecutive steps (HIP events at the end of each step, on its instance's stream)"},
+                                      "HIP events per replay on the launch stream, a joint replay's time divided by its %d steps" % D},
                 "end_to_end_tflops": round(eng.flops_per_image * value / world / 1e12, 2),
                 "activation_mb": round(eng.activation_bytes / 1e6, 1)}
         if not args.no_profile:
             line["roofline"] = roofline(eng, args.arch, B, wall_ms=ms_step)
             # DVFS (MI355X_MICROARCH.md: short bursts clock higher): the same step over >= 1000 replays AFTER the timed region
             n_sus = max(1000, args.steps)
-            sus = timed_replays(engs, streams, n_sus, 0)
+            sus = timed_replays(eng, pipe, n_sus, 0)
             line["sustained"] = {"replays": n_sus, "seconds": round(sus, 3), "images_per_sec": round(B * n_sus / sus, 1),
                                  "ms_per_step": round(sus / n_sus * 1e3, 3), "steps_in_flight": D,
                                  "note": "graph replays after the timed region, one host sync at the end (no gather, no clone)"}
             # what rounds 1-4 timed: ONE instance, one replay after the other on the current stream (same kernels, same bits)
             n_one = max(100, args.steps)
-            one = timed_replays(engs[:1], [None], n_one, 3)
+            one = timed_replays(eng, None, n_one, 3)
             line["one_step_in_flight"] = {"replays": n_one, "images_per_sec": round(B * n_one / one, 1), "ms_per_step": round(one / n_one * 1e3, 3)}
             # ---- decode alone (latency-bound; reported as us/batch next to its HBM GB/s) ------------------
             hm, wh, hps, reg, hm_hp, hp_offset = eng.outputs

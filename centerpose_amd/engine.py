@@ -856,46 +856,64 @@ class Engine:
 
 
 class EnginePipeline:
-    """`depth` instances of ONE compiled network, replayed round-robin, each on its own HIP stream: `depth` steps in flight.
+    """`depth` independent steps in ONE replay: `depth` instances of one compiled network (own activations, own static input /
+    output buffers; packed constants shared through `const_cache`) whose launch lists are scheduled TOGETHER on the two capture
+    streams and captured into one hipGraph.
 
     Why: a step is a dependency chain of ~100 kernel launches.  rocprofv3 (profiles/r5_two_stream_overlap.txt) shows, per 7.3 ms step of
-    dla_34 B=16, 0.85 ms with NO kernel running (92 gaps between dependent graph nodes), 4.3 ms with exactly one (tails of one launch
-    cannot be filled by the next, which depends on it) and only 3.4 ms with the two capture streams both busy; hrnet / res_50 at B=8
-    under-fill the chip in most launches.  A second, independent step has no dependency on the first: its kernels fill those holes.
-    Same kernels, same bits (every instance owns its activations, static input / output buffers and captured two-stream hipGraph;
-    the packed constants and the launch schedule are shared through `const_cache` / `sched_cache`); what changes is batch LATENCY
-    (~depth x) against THROUGHPUT (measured: dla_34 B=16 +3 %, res_50 B=8 +12 %, hrnet B=8 +26 %).  The reference runs one image at
-    a time, synchronously (lib/detectors/base_detector.py:79-140); this is the serving-side overlap it leaves on the table.
+    dla_34 B=16, 0.85 ms with NO kernel running (92 gaps between dependent graph nodes), 4.3 ms with exactly one kernel (the tail of a
+    launch cannot be filled by the next one, which depends on it) and only 3.4 ms with both capture streams busy; hrnet / res_50 at
+    B=8 under-fill the chip in most launches.  A second step has no dependency on the first: the critical-path list scheduler
+    (`Engine.plan_schedule`) that already places one step's independent branches on two streams now has two whole chains to
+    interleave, and the holes of one are filled by the kernels of the other.  Same kernels, same bits per step; batch LATENCY
+    roughly doubles, THROUGHPUT rises.  The reference runs one image at a time, synchronously (lib/detectors/base_detector.py:79-140).
 
-    `process(images=None)` enqueues one step on the next instance's stream and returns `(outputs, dets, stream)`: static buffers of
-    that instance, valid once `stream` has been waited for (`torch.cuda.current_stream().wait_stream(stream)` or a device
-    synchronisation) and until the instance's next turn (`depth` calls later)."""
+    Not done with two graphs on two user streams: whether two hipGraph replays on different streams overlap at all depends on which
+    hardware queues the streams (and each graph's internal branch streams) land on -- measured on ROCm 7.2 / MI355X: 5 of 45 stream
+    pairs overlap (hrnet B=8 1 560 -> 1 970 img/s), the other 40 serialise, and probing pairs by replaying one graph exec on many
+    streams segfaults inside hipGraphLaunch (tools/pipeline_try3.py).  One graph has none of that.
 
-    def __init__(self, arch, state_dict, batch, height=512, width=512, device="cuda", depth=2, **kw):
+    `process_all(images=None)` -> [(outputs, dets)] * depth (static buffers of the instances, overwritten by the next call)."""
+
+    def __init__(self, arch, state_dict, batch, height=512, width=512, device="cuda", depth=2, engines=None, **kw):
         if depth < 1:
             raise ValueError("depth >= 1")
-        cc = kw.pop("const_cache", None)
-        sc = kw.pop("sched_cache", None)
-        cc = {} if cc is None else cc
-        sc = {} if sc is None else sc
-        self.engines = [Engine(arch, state_dict, batch, height, width, device, const_cache=cc, sched_cache=sc, **kw) for _ in range(depth)]
-        dev = self.engines[0].device
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(depth)]
-        self.depth, self.turn = depth, 0
+        if engines is None:
+            cc = kw.pop("const_cache", None)
+            cc = {} if cc is None else cc
+            kw.pop("sched_cache", None)
+            engines = [Engine(arch, state_dict, batch, height, width, device, const_cache=cc, **kw) for _ in range(depth)]
+        self.engines, self.depth = list(engines), len(engines)
+        if any(e.dets is None for e in self.engines):
+            raise _lib.CenterposeHipError("EnginePipeline needs engines built with decode_k")
+        first = self.engines[0]
+        # the joint plan: an Engine-shaped view over ALL instances' launch records (no data dependency between instances: their
+        # buffers are disjoint, the shared constants are only read), scheduled and captured by the Engine machinery itself
+        joint = object.__new__(Engine)
+        joint.__dict__.update(first.__dict__)
+        joint.launches = [l for e in self.engines for l in e.launches]
+        joint.emission = joint.launches
+        joint.graph, joint.capture_mode, joint.sched_cache = None, None, None
+        joint.stream_plan = None
+        joint.use_graph = True
+        joint.activation_bytes = sum(e.activation_bytes for e in self.engines)
+        self.joint = joint
 
-    def next_slot(self):
-        """(engine, stream) of the next step; advances the round-robin."""
-        i = self.turn % self.depth
-        self.turn += 1
-        return self.engines[i], self.streams[i]
+    @property
+    def capture_mode(self):
+        return self.joint.capture_mode
 
-    def process(self, images=None):
-        eng, s = self.next_slot()
-        s.wait_stream(torch.cuda.current_stream(eng.device))      # the caller's writes to `images` (and the previous owner of this slot)
-        with torch.cuda.stream(s):
-            outs, dets = eng.process(eng.input if images is None else images)
-        return outs, dets, s
-
-    def synchronize(self):
-        for s in self.streams:
-            s.synchronize()
+    def process_all(self, images=None):
+        """One replay = one step of EVERY instance.  images: None (the instances' own static inputs) or `depth` tensors."""
+        if images is not None:
+            if len(images) != self.depth:
+                raise ValueError("expected %d image batches" % self.depth)
+            for e, x in zip(self.engines, images):
+                if tuple(x.shape) != tuple(e.input.shape):
+                    raise ValueError("engine was planned for input %s, got %s" % (tuple(e.input.shape), tuple(x.shape)))
+                if x.data_ptr() != e.input.data_ptr():
+                    e.input.copy_(x)
+        if self.joint.graph is None:
+            self.joint.capture()
+        self.joint.graph.replay()
+        return [(e.outputs, e.dets) for e in self.engines]

@@ -626,14 +626,14 @@ def test_timed_configuration_parity(arch, B):
 
 @pytest.mark.parametrize("arch,depth", [("dla_34", 2), ("hrnet", 3)])
 def test_steps_in_flight_same_bits_as_one_after_the_other(arch, depth):
-    """engine.EnginePipeline (what bench.py times since round 5: `depth` plan instances replayed round-robin on `depth` streams, so the
-    next step's kernels fill the launch gaps and tails of the current one): every step's heads and detections are BIT-IDENTICAL to
-    the same images through a single engine, one replay after the other -- with the instances' constants / schedule shared, inputs
-    changing every step, and the slot of step i reused by step i + depth."""
+    """engine.EnginePipeline (what bench.py times since round 5: `depth` plan instances whose launch lists are scheduled TOGETHER and
+    captured into one hipGraph, so that one step's kernels fill the launch gaps and chain tails of the other): every step's heads
+    and detections are BIT-IDENTICAL to the same images through a single engine, one step per replay -- inputs changing every
+    replay, the graph replayed several times."""
     from centerpose_amd import engine, synth
     sd = synth.make_state_dict(arch, seed=4)
     B, H, W = 2, 128, 96
-    imgs = [synth.make_images(B, H, W, seed=20 + i).cuda() for i in range(7)]
+    imgs = [synth.make_images(B, H, W, seed=20 + i).cuda() for i in range(2 * depth)]
     one = engine.Engine(arch, sd, B, H, W, use_graph=True, decode_k=100)
     want = []
     for x in imgs:
@@ -641,18 +641,19 @@ def test_steps_in_flight_same_bits_as_one_after_the_other(arch, depth):
         want.append([t.clone() for t in outs] + [dets.clone()])
     torch.cuda.synchronize()
     pipe = engine.EnginePipeline(arch, sd, B, H, W, depth=depth, use_graph=True, decode_k=100)
-    assert len({id(e) for e in pipe.engines}) == depth and len({e.input.data_ptr() for e in pipe.engines}) == depth
-    got, pending = [], []
-    for x in imgs:
-        outs, dets, s = pipe.process(x)
-        with torch.cuda.stream(s):                                  # the caller's copy, ordered behind the step on ITS stream
-            pending.append(([t.clone() for t in outs] + [dets.clone()], s))
-    for g, s in pending:
-        s.synchronize()
-        got.append(g)
-    assert all(e.capture_mode == "2-stream" for e in pipe.engines)
+    assert len({e.input.data_ptr() for e in pipe.engines}) == depth and len(pipe.joint.launches) == depth * len(one.launches)
+    got = []
+    for r in range(2):
+        res = pipe.process_all(imgs[r * depth:(r + 1) * depth])
+        torch.cuda.synchronize()
+        got += [[t.clone() for t in outs] + [dets.clone()] for outs, dets in res]
+    assert pipe.capture_mode == "2-stream", pipe.capture_mode
     for i, (g, w) in enumerate(zip(got, want)):
         assert all(torch.equal(a, b) for a, b in zip(g, w)), "step %d differs" % i
+    # the joint schedule really interleaves the instances: both capture streams carry launches of more than one instance
+    owner = {id(l): k for k, e in enumerate(pipe.engines) for _, _, _, l in e.launches}
+    per_stream = [{owner[id(l)] for (_, _, _, l), st in zip(pipe.joint.launches, pipe.joint.stream_of_launch) if st == q} for q in (0, 1)]
+    assert all(len(x) >= 2 for x in per_stream), per_stream
 
 
 def test_model_shares_constants_and_schedules_between_shapes():
