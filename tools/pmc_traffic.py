@@ -17,7 +17,7 @@ FAMILY = (("dcn_igemm_kernel", "cp_dcn_v2_f32"), ("conv3x3_wino", "cp_conv3x3_wi
 def one_pass(counter, args):
     d = os.path.join(os.environ.get("GRAFT_REPO_ROOT", ROOT), "gpurun_out", "pmc_" + counter)
     cmd = ["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--",
-           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--no-profile"] + args
+           sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-graph", "--no-cpu-baseline", "--no-profile", "--no-other-configs"] + args
     subprocess.run(cmd, env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=False, text=True)
     acc = {}
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
