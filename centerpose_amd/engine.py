@@ -227,7 +227,7 @@ class PlanBuilder(nets.Graph):
         if u is not None:
             self.add_wino(conv, flops, srcs[0], wp, u, sc, sh, out.t, out.t.shape[3], self.act_code(relu), rt)
             return out
-        S = ops.conv_ksplit(self.B * Ho * Wo, wp.shape[0], wp.shape[1]) \
+        S = ops.conv_ksplit(ops.rule_batch(self.B) * Ho * Wo, wp.shape[0], wp.shape[1]) \
             if (self.conv_splitk and not stem and len(xs) == 1 and res is None and not (k == 3 and stride == 1 and pad == 1)) else 1
         if S > 1:
             # small-M launch (res_50 layer4 at B = 8: 256 blocks on 256 CUs): split-K into a workspace of raw partial sums, then the
@@ -342,7 +342,7 @@ class PlanBuilder(nets.Graph):
             self.add("conv", conv + ".conv_offset_mask", 2 * x.H * x.W * 27 * x.C * 9,
                      ops.conv2d_launch([x.t], wom, som, hom, om.t, kh=3, kw=3, stride=1, pad=1, cout=32))
         flops = 2 * x.H * x.W * co * x.C * 9
-        S = ops.dcn_ksplit(self.B * x.H * x.W, wp.shape[0]) if self.dcn_splitk else 1
+        S = ops.dcn_ksplit(ops.rule_batch(self.B) * x.H * x.W, wp.shape[0]) if self.dcn_splitk else 1
         if S > 1:
             # small-M layer (512 -> 256 @16x16 at B = 16 is 256 blocks of 288 k-steps on 256 CUs): split-K over the taps into a
             # workspace of raw partial sums, then a fixed-order reduction + BN + ReLU (deterministic; two launches)

@@ -182,6 +182,22 @@ def _ld(t):
     return t.stride(2)
 
 
+# ---- batch invariance ---------------------------------------------------------------------------------------------------
+# Several launch rules look at how many blocks a launch has, i.e. at the BATCH: F(2x4) vs F(2x2) Winograd (wino24_wanted), the F(2x4)
+# head kernel, the fused head launch, the split-K / split-C factors.  F(2x4) has ~4x the rounding error of F(2x2)
+# (profiles/r4_wino_error_vs_fp64.txt) and a split changes the summation order, so by DEFAULT the same image gives (slightly: <= 1e-4
+# of the head scale, tests/test_engine_hip.py) different bits at B = 8 and B = 16.  CP_BATCH_INVARIANT=1 evaluates every such rule
+# as if the batch were 1: one switch, the same kernel / split for an image whatever batch it travels in (bit-for-bit batch
+# invariance; slower at large batches, whose launches are then split more than they need to be).  The tile choices made inside
+# the C launchers (64x64 vs 128x64 / 64x128) depend on the batch too but not the arithmetic: same k order, same bits.
+BATCH_INVARIANT = os.environ.get("CP_BATCH_INVARIANT", "0") == "1"
+
+
+def rule_batch(B):
+    """the batch a block-count rule may look at: B, or 1 under CP_BATCH_INVARIANT=1"""
+    return 1 if BATCH_INVARIANT else B
+
+
 # ---- opt-in split-bf16 mode of the generic implicit GEMM (conv_igemm_bf16x3.hip; VERDICT r4 #1) -------------------------------
 # CP_SPLIT_BF16=1 (or ops.SPLIT_BF16 = True before a plan is compiled): generic NHWC launches whose padded output channels are a
 # multiple of 64 run as an fp32-EQUIVALENT 3-term bf16 split on the bf16 matrix pipe (six bf16 MFMAs per fp32 product tile, fp32
@@ -288,7 +304,7 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
         assert len(srcs) == 1 and not in_nchw
         return Launch("cp_conv3x3_winograd_f32", d, [srcs[0], wino, scale, shift, res, out])
     if (SPLIT_BF16 if split_bf16 is None else split_bf16) and tile == 0 and not in_nchw:
-        bn = split_bf16_tile(B * Ho * Wo, d.ldw, nsub, ksplit, force=split_bf16 is True)
+        bn = split_bf16_tile(rule_batch(B) * Ho * Wo, d.ldw, nsub, ksplit, force=split_bf16 is True)
         c16 = kh == 3 and kw == 3 and len(srcs) == 1 and srcs[0].shape[3] == 16 and cout <= 32      # stays on conv3x3_c16_kernel
         if bn is not None and not c16 and all(s.data_ptr() % 16 == 0 for s in srcs):
             d.tile = SPLIT_BF16_TILE[bn]
@@ -347,6 +363,7 @@ def head3x3_1x1_eligible(x, hc, n2):
     registers; 3..34: second MFMA phase for the first 32 + registers for the rest), and enough spatial tiles to fill the chip
     (the V-stationary Winograd kernel's own condition)."""
     B, H, W, C = x.shape
+    B = rule_batch(B)
     return C == 64 and hc % 32 == 0 and hc >= 128 and 1 <= n2 <= 34 and B * ((H + 7) // 8) * ((W + 15) // 16) >= 512
 
 
@@ -356,6 +373,7 @@ def head_wino24_wanted(x, n2):
     (same-process A/B, tools/head_ab.py, B = 16: n2 = 1 0.261 vs 0.288 ms, n2 = 2 0.271 vs 0.293, n2 = 17 0.313 vs 0.335; n2 = 34 0.364
     vs 0.362: hps keeps the F(2x2) kernel)."""
     B, H, W, _ = x.shape
+    B = rule_batch(B)
     mode = os.environ.get("CP_HEAD24", "1")
     if mode == "0" or B * ((H + 15) // 16) * ((W + 15) // 16) < 256:
         return False
@@ -425,7 +443,7 @@ def wino24_wanted(B, H, W, cin, cout):
     if os.environ.get("CP_WINO24", "1") == "0" or cin % 16 or cin < 32:
         return False
     minc, mincout, minblocks = (int(v) for v in os.environ.get("CP_WINO24_RULE", "32,16,256").split(","))
-    blocks = B * ((H + 15) // 16) * ((W + 15) // 16) * ((cout + 31) // 32)
+    blocks = rule_batch(B) * ((H + 15) // 16) * ((W + 15) // 16) * ((cout + 31) // 32)
     return cin >= minc and cout >= mincout and blocks >= minblocks
 
 
@@ -463,7 +481,7 @@ def wino_ksplit(B, H, W, cin, cout):
     """Split-C factor for a Winograd 3x3 launch without residual: the 8x16-pixel x 32-channel blocks of a small map cannot fill
     256 CUs (512 -> 27 @16x16, B = 16: 32 blocks walking 32 channel stages).  S = smallest power of two that gives >= 512 blocks
     while every split keeps >= 4 stages of 16 channels; 1 when the launch already has >= 256 blocks."""
-    blocks = B * ((H + 7) // 8) * ((W + 15) // 16) * ((cout + 31) // 32)
+    blocks = rule_batch(B) * ((H + 7) // 8) * ((W + 15) // 16) * ((cout + 31) // 32)
     stages = cin // 16
     S = 1
     while blocks * S < 512 and stages // (2 * S) >= 4:

@@ -501,6 +501,36 @@ def test_full_size_batch_invariance_and_scaling_property(monkeypatch):
     assert torch.equal(o1 * 4.0, o2)
 
 
+@pytest.mark.parametrize("arch,hw", [("dla_34", (512, 512)), ("hrnet", (256, 384))])
+def test_batch_invariant_switch_pins_every_batch_dependent_rule(arch, hw, monkeypatch):
+    """CP_BATCH_INVARIANT=1 (ops.BATCH_INVARIANT): ONE switch instead of the five the two tests around this one set -- every
+    rule that looks at a launch's block count (F(2x4) vs F(2x2), the head kernels, split-K / split-C factors) is evaluated as if the
+    batch were 1, so an image's head maps are the same BITS whether it travels in a batch of 6, 3 or 1; the default plan (rules at
+    the real batch) stays within 1e-4 of the head scale of it."""
+    from centerpose_amd import engine, ops, synth
+    sd = synth.make_state_dict(arch)
+    x = synth.make_images(6, hw[0], hw[1], seed=9).cuda()
+    monkeypatch.setattr(ops, "BATCH_INVARIANT", True)
+    e6 = engine.Engine(arch, sd, 6, hw[0], hw[1])
+    full = [t.clone() for t in e6(x)]
+    names6 = [(n, l.fn) for _, n, _, l in e6.emission]
+    del e6
+    for b in (3, 1):
+        eb = engine.Engine(arch, sd, b, hw[0], hw[1])
+        for i in range(0, 6, b):
+            part = eb(x[i:i + b])
+            torch.cuda.synchronize()
+            assert all(torch.equal(f[i:i + b], p) for f, p in zip(full, part)), "B=%d, images %d.." % (b, i)
+        assert [(n, l.fn) for _, n, _, l in eb.emission] == names6                     # the same launch list at every batch
+        del eb
+    monkeypatch.setattr(ops, "BATCH_INVARIANT", False)
+    ed = engine.Engine(arch, sd, 6, hw[0], hw[1])
+    dflt = ed(x)
+    torch.cuda.synchronize()
+    for a, b in zip(dflt, full):
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item())
+
+
 @pytest.mark.parametrize("arch", ["res_50", "hrnet"])
 def test_full_size_b8_properties(arch, monkeypatch):
     """BASELINE.json configs[1] (res_50 512x512 batch 8) and configs[4]'s per-GPU shape (hrnet 512x512 batch 8): the oracle is
