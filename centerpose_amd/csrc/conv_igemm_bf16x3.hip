@@ -6,7 +6,7 @@
 // cross products  x1y1 + (x1y2 + x2y1) + (x1y3 + x2y2 + x3y1)  are issued on v_mfma_f32_32x32x16_bf16 with fp32 accumulate.  A
 // bf16 x bf16 product is exact in fp32; the three dropped products (x2y3, x3y2, x3y3) are <= 2^-24 + 2^-24 + 2^-32 relative to
 // |xy| -- the size of ONE fp32 rounding of the product, which the f32 MFMA / an fmaf chain commits on every term anyway.  Measured
-// error against an fp64 convolution: tools/bf16x3_check.py (profiles/r5_bf16x3_error_vs_fp64.txt).
+// error against an fp64 convolution: tools/bf16x3_ab.py (profiles/r5_bf16x3_ab_*.txt).
 // Rate: 6 bf16 MFMAs (32 cycles each, K = 16) replace 8 f32 MFMAs (64 cycles each, K = 2): 192 vs 512 matrix-pipe cycles per
 // 32 x 32 x 16 tile step = 2.67x, ceiling 2516 / 6 = 419 TFLOP/s fp32-equivalent; and the split's VALU work runs BESIDE the
 // bf16 matrix pipe (the f32 MFMA shares the fp32 FMA lanes with the VALU: DESIGN 7.2).
@@ -21,7 +21,8 @@
 //     distinct banks); a lane's MFMA operand (row i = lane & 31, k-group g = lane >> 5: 8 consecutive k) is one ds_read_b128
 //     per term; A and B use the same k <-> position map, so the products pair up whatever the hardware's k order inside the
 //     instruction is;
-//   * a wave owns a (BM/2) x (BN/2) tile: 64 x 64 -> 12 fragment reads feed 24 MFMAs.
+//   * a wave owns a (BM/2) x (BN/2) tile: 64 x 64 -> 12 fragment reads feed 24 MFMAs; the 64-row tiles (32 x 64 / 32 x 32 per wave, a thread
+//     stages a 4-channel quarter of a pixel) exist for the small-M layers, where 128-row tiles leave CUs without a block.
 #include "igemm.h"
 
 typedef __bf16 sb_bf16x8 __attribute__((ext_vector_type(8)));
@@ -57,14 +58,17 @@ __device__ __forceinline__ f32x16 sb_mfma(sb_v4u a, sb_v4u b, f32x16 c)
 template <int BM, int BN>
 struct SbTile {
     using T = IgTile<BM, BN, 2, 2, 32>;
-    static constexpr int A_SLOTS = BM * 2 / IG_THREADS;                              // (pixel, half) pairs per thread per k-step
+    // A staging: BM >= 128: thread = (pixel, 8-channel HALF), BM / 128 pixels per thread, two float4 each;
+    //            BM == 64:  thread = (pixel, 4-channel QUARTER), one float4 (the small-M layers: 32x32 / 16x16 maps at B = 8)
+    static constexpr bool QUARTER = BM == 64;
+    static constexpr int A_SLOTS = QUARTER ? 1 : BM * 2 / IG_THREADS;
     static constexpr int B_CH = BN * 6;                                              // 16-byte chunks of one B slice
     static constexpr int B_SLOTS = (B_CH + IG_THREADS - 1) / IG_THREADS;
     static constexpr int A_DW = BM * SB_LDR, B_DW = BN * SB_LDR;
     static constexpr int MAIN_BYTES = 2 * (A_DW + B_DW) * 4;
     static constexpr int NHWC_BYTES = MAIN_BYTES > T::EPV_BYTES ? MAIN_BYTES : T::EPV_BYTES;
     static constexpr int NCHW_BYTES = MAIN_BYTES > T::EPI_BYTES ? MAIN_BYTES : T::EPI_BYTES;
-    static_assert(A_SLOTS >= 1, "BM >= 128");
+    static_assert(BM == 64 || BM % 128 == 0, "BM = 64 or a multiple of 128");
 };
 
 // MFMAs of one k-step held in LDS; `mid` (the next slice's global loads) is called after half of the output tiles
@@ -143,12 +147,13 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_bf16x3_kernel(const ConvA
 
     const int ks0 = ksp * nk_all / SK, nk = (ksp + 1) * nk_all / SK;
 
-    // ---- A producer: thread -> (pixel, 8-channel half) ------------------------------------------------------------------
-    const int q = tid & 1;
+    // ---- A producer: thread -> (pixel, 8-channel half), or (pixel, 4-channel quarter) for the 64-row tile ------------------
+    constexpr int QS = S::QUARTER ? 4 : 2;                      // threads per pixel
+    const int q = tid & (QS - 1);
     SbPix ps[S::A_SLOTS];
 #pragma unroll
     for (int s = 0; s < S::A_SLOTS; ++s) {
-        const int m = m0 + (tid >> 1) + s * 128;
+        const int m = m0 + tid / QS + s * 128;
         if (m < a.M) {
             const int b = m / HoWo, p = m - b * HoWo, oy = p / a.Wo, ox = p - oy * a.Wo;
             ps[s].boff = b * a.H * a.W;
@@ -176,7 +181,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_bf16x3_kernel(const ConvA
             for (int s = 0; s < S::A_SLOTS; ++s) {
                 const int iy = ps[s].iy0 + ky, ix = ps[s].ix0 + kx;
                 const bool ok = ps[s].boff >= 0 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-                aoff[s] = ok ? ((unsigned)(ps[s].boff + iy * a.W + ix) * (unsigned)ld + (unsigned)q * 8u) * 4u : 0u;
+                aoff[s] = ok ? ((unsigned)(ps[s].boff + iy * a.W + ix) * (unsigned)ld + (unsigned)q * (S::QUARTER ? 4u : 8u)) * 4u : 0u;
                 aok[s] = ok;
             }
         }
@@ -184,7 +189,7 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_bf16x3_kernel(const ConvA
 #pragma unroll
         for (int s = 0; s < S::A_SLOTS; ++s) {
             ar[s][0] = ig_ldg4(reinterpret_cast<const float*>(xs + aoff[s]));
-            ar[s][1] = ig_ldg4(reinterpret_cast<const float*>(xs + aoff[s]) + 4);
+            if constexpr (!S::QUARTER) ar[s][1] = ig_ldg4(reinterpret_cast<const float*>(xs + aoff[s]) + 4);
         }
     };
     auto advance = [&]() __attribute__((always_inline)) {
@@ -206,14 +211,24 @@ __global__ __launch_bounds__(IG_THREADS, 2) void igemm_bf16x3_kernel(const ConvA
     auto store_ab = [&](unsigned* As, unsigned* Bs) __attribute__((always_inline)) {
 #pragma unroll
         for (int s = 0; s < S::A_SLOTS; ++s) {
-            const float4 v0 = aok[s] ? ar[s][0] : make_float4(0.f, 0.f, 0.f, 0.f), v1 = aok[s] ? ar[s][1] : make_float4(0.f, 0.f, 0.f, 0.f);
-            unsigned t1[4], t2[4], t3[4];
-            sb_split2(v0.x, v0.y, t1[0], t2[0], t3[0]); sb_split2(v0.z, v0.w, t1[1], t2[1], t3[1]);
-            sb_split2(v1.x, v1.y, t1[2], t2[2], t3[2]); sb_split2(v1.z, v1.w, t1[3], t2[3], t3[3]);
-            unsigned* row = As + ((tid >> 1) + s * 128) * SB_LDR + q * 4;
-            *reinterpret_cast<sb_v4u*>(row) = (sb_v4u){t1[0], t1[1], t1[2], t1[3]};
-            *reinterpret_cast<sb_v4u*>(row + 8) = (sb_v4u){t2[0], t2[1], t2[2], t2[3]};
-            *reinterpret_cast<sb_v4u*>(row + 16) = (sb_v4u){t3[0], t3[1], t3[2], t3[3]};
+            const float4 v0 = aok[s] ? ar[s][0] : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (S::QUARTER) {
+                unsigned t1[2], t2[2], t3[2];
+                sb_split2(v0.x, v0.y, t1[0], t2[0], t3[0]); sb_split2(v0.z, v0.w, t1[1], t2[1], t3[1]);
+                unsigned* row = As + (tid >> 2) * SB_LDR + q * 2;
+                *reinterpret_cast<uint2*>(row) = make_uint2(t1[0], t1[1]);
+                *reinterpret_cast<uint2*>(row + 8) = make_uint2(t2[0], t2[1]);
+                *reinterpret_cast<uint2*>(row + 16) = make_uint2(t3[0], t3[1]);
+            } else {
+                const float4 v1 = aok[s] ? ar[s][1] : make_float4(0.f, 0.f, 0.f, 0.f);
+                unsigned t1[4], t2[4], t3[4];
+                sb_split2(v0.x, v0.y, t1[0], t2[0], t3[0]); sb_split2(v0.z, v0.w, t1[1], t2[1], t3[1]);
+                sb_split2(v1.x, v1.y, t1[2], t2[2], t3[2]); sb_split2(v1.z, v1.w, t1[3], t2[3], t3[3]);
+                unsigned* row = As + ((tid >> 1) + s * 128) * SB_LDR + q * 4;
+                *reinterpret_cast<sb_v4u*>(row) = (sb_v4u){t1[0], t1[1], t1[2], t1[3]};
+                *reinterpret_cast<sb_v4u*>(row + 8) = (sb_v4u){t2[0], t2[1], t2[2], t2[3]};
+                *reinterpret_cast<sb_v4u*>(row + 16) = (sb_v4u){t3[0], t3[1], t3[2], t3[3]};
+            }
         }
 #pragma unroll
         for (int s = 0; s < S::B_SLOTS; ++s) {
@@ -275,6 +290,8 @@ int cp_launch_conv_bf16x3(const ConvArgs& a, int tile, hipStream_t s)
     switch (tile) {
         case 3128128: return launch_sb<128, 128>(a, s);
         case 3128064: return launch_sb<128, 64>(a, s);
+        case 3064128: return launch_sb<64, 128>(a, s);
+        case 3064064: return launch_sb<64, 64>(a, s);
         default: cp_set_error("conv2d (split-bf16): unknown tile %d", tile); return 1;
     }
 }

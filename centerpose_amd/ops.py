@@ -203,7 +203,7 @@ def rule_batch(B):
 # multiple of 64 run as an fp32-EQUIVALENT 3-term bf16 split on the bf16 matrix pipe (six bf16 MFMAs per fp32 product tile, fp32
 # accumulate, dropped terms <= 2^-24 relative).  Never the default; the timed configuration and `dtype: "f32"` stay on the f32 MFMA.
 SPLIT_BF16 = os.environ.get("CP_SPLIT_BF16", "0") == "1"
-SPLIT_BF16_TILE = {128: 3128128, 64: 3128064}          # cp_conv_desc.tile codes by N tile
+SPLIT_BF16_TILES = ((128, 128), (128, 64), (64, 128), (64, 64))      # (BM, BN) instantiations; cp_conv_desc.tile = 3000000 + BM * 1000 + BN
 
 
 def split_bf16_weight(wp, ldw):
@@ -218,27 +218,32 @@ def split_bf16_weight(wp, ldw):
     return wb
 
 
-def split_bf16_tile(M, ldw, nsub=1, ksplit=1, force=False):
-    """N tile of the split-bf16 kernel for a launch with M output pixels per sub-convolution, or None = the launch stays on the f32
-    kernel.  The first version of the kernel only has 128-row tiles: it measured 1.05-1.5x the f32 kernel wherever that tiling gives
-    every CU two blocks and 0.62-0.82x where it does not (profiles/r5_bf16x3_ab_v1.txt), so the rule is: 128 x 128 when it makes
-    >= MINBLOCKS blocks, else 128 x 64 when that does, else f32; split-K launches (small M by construction) stay on the f32 kernel.
-    CP_SPLIT_BF16_TILE forces an N tile (tests, A/B), CP_SPLIT_BF16_MINBLOCKS the floor (default 512; 0 = every eligible launch).
-    `force` (a launch built with split_bf16=True): no floor, split-K allowed."""
+def split_bf16_tile(M, ldw, nsub=1, ksplit=1, force=False, K=None):
+    """Tile code of the split-bf16 kernel for a launch with M output pixels per sub-convolution, or None = the launch stays on the f32
+    kernel.  Rule, from the same-process A/B of all four tiles on 20 layer shapes (profiles/r5_bf16x3_ab_v2.txt): the first of 128x128,
+    64x128, 64x64 that still makes >= MINBLOCKS blocks (a wider N tile stages the activations once for more outputs; 128x64 is never
+    the best tile; every tile loses, 0.62-0.86x, where it cannot give every CU two blocks); K <= 64 (four k-steps) -> 64x64; no tile
+    reaches the floor -> f32; split-K launches (small M by construction) stay on the f32 kernel.
+    CP_SPLIT_BF16_TILE forces a tile ("BMxBN", or "BN" = 128 x BN; tests, A/B), CP_SPLIT_BF16_MINBLOCKS the floor (default 512; 0 =
+    every eligible launch).  `force` (a launch built with split_bf16=True): no floor, split-K allowed."""
     if ldw % 64:
         return None
+    code = lambda bm, bn: 3000000 + bm * 1000 + bn
     forced = os.environ.get("CP_SPLIT_BF16_TILE")
     if forced:
-        return int(forced) if ldw % int(forced) == 0 else 64
+        bm, bn = (int(v) for v in forced.split("x")) if "x" in forced else (128, int(forced))
+        return code(bm, bn if ldw % bn == 0 else 64)
+    blocks = lambda bm, bn: ((M + bm - 1) // bm) * max(1, nsub) * max(1, ksplit) * (ldw // bn)
     floor = 0 if force else int(os.environ.get("CP_SPLIT_BF16_MINBLOCKS", "512"))
     if floor == 0:
-        return 128 if ldw % 128 == 0 and ((M + 127) // 128) * max(1, nsub) * max(1, ksplit) * (ldw // 128) >= 256 else 64
+        return code(128, 128) if ldw % 128 == 0 and blocks(128, 128) >= 256 else code(128, 64)
     if ksplit > 1:
         return None
-    mt = ((M + 127) // 128) * max(1, nsub)
-    if ldw % 128 == 0 and mt * (ldw // 128) >= floor:
-        return 128
-    return 64 if mt * (ldw // 64) >= floor else None
+    order = ((64, 64),) if K is not None and K <= 64 else ((128, 128), (64, 128), (64, 64))
+    for bm, bn in order:
+        if ldw % bn == 0 and blocks(bm, bn) >= floor:
+            return code(bm, bn)
+    return None
 
 
 def conv2d(srcs, wp, scale, shift, out, **kw):
@@ -304,10 +309,10 @@ def conv2d_launch(srcs, wp, scale, shift, out, *, kh, kw, stride=1, pad=0, cout,
         assert len(srcs) == 1 and not in_nchw
         return Launch("cp_conv3x3_winograd_f32", d, [srcs[0], wino, scale, shift, res, out])
     if (SPLIT_BF16 if split_bf16 is None else split_bf16) and tile == 0 and not in_nchw:
-        bn = split_bf16_tile(rule_batch(B) * Ho * Wo, d.ldw, nsub, ksplit, force=split_bf16 is True)
+        code = split_bf16_tile(rule_batch(B) * Ho * Wo, d.ldw, nsub, ksplit, force=split_bf16 is True, K=d.K)
         c16 = kh == 3 and kw == 3 and len(srcs) == 1 and srcs[0].shape[3] == 16 and cout <= 32      # stays on conv3x3_c16_kernel
-        if bn is not None and not c16 and all(s.data_ptr() % 16 == 0 for s in srcs):
-            d.tile = SPLIT_BF16_TILE[bn]
+        if code is not None and not c16 and all(s.data_ptr() % 16 == 0 for s in srcs):
+            d.tile = code
             wp = split_bf16_weight(wp, d.ldw)
     return Launch("cp_conv2d_f32", d, list(srcs) + [None] * (4 - len(srcs)) + [wp, scale, shift, res, out])
 

@@ -51,7 +51,7 @@ typedef struct cp_conv_desc {
     int OH, OW, osy, osx, ooy, oox;   /* output pixel = (oy*osy+ooy, ox*osx+oox) inside [OH,OW] */
     int act;
     int inNCHW;               /* 1: src[0] is the NCHW network input [B,srcC[0],H,W] (base_detector.py:53-58) */
-    int tile;                 /* 0 = auto; BM*1000+BN to force a kernel instantiation; 3000000 + BM*1000 + BN (3128128, 3128064): the
+    int tile;                 /* 0 = auto; BM*1000+BN to force a kernel instantiation; 3000000 + BM*1000 + BN (BM, BN in {128, 64}): the
                                  OPT-IN split-bf16 kernel below -- `w` is then cp_split_bf16_weights_f32's output, NHWC sources only */
     int nsub;                 /* 0 / 1: one convolution.  4: the four sub-pixel 2x2 convolutions of a dense ConvTranspose2d(k4,s2,p1)
                                  (msra_resnet.py:168-193) in ONE launch: w = [4][ldw][K] (sub g = py*2+px), py = px = 1, osy = osx = 2,
@@ -75,7 +75,7 @@ int cp_conv2d_group_f32(const cp_conv_desc* d, int n, const float* const* src, c
  * arithmetic is fp32 end to end: DCNv2/src/cuda/dcn_v2_cuda.cu:58): every fp32 operand is three bf16 terms (8+8+8 significand bits,
  * exact), six bf16 MFMAs with fp32 accumulate per product tile, dropped terms <= 2^-24 relative.  Activations are split in the
  * kernel; weights once, here: w [rows][K] (rows = nsub * ldw, the layout cp_conv2d_f32 takes) -> wb, cp_split_bf16_weight_floats
- * (rows, K) floats holding bf16 [nsub][K/16][ldw][3][16].  Pass wb as `w` together with tile = 3128128 / 3128064 (ldw % 128 / % 64). */
+ * (rows, K) floats holding bf16 [nsub][K/16][ldw][3][16].  Pass wb as `w` together with tile = 3128128 / 3064128 (ldw % 128 == 0) / 3128064 / 3064064. */
 size_t cp_split_bf16_weight_floats(int rows, int K);
 int cp_split_bf16_weights_f32(const float* w, int rows, int ldw, int K, float* wb, void* stream);
 

@@ -59,6 +59,8 @@ def test_conv_bn_relu_residual(cin, cout, k, s, p, hw, tile):
 @pytest.mark.parametrize("cin,cout,k,s,p,hw,bn_tile", [
     (32, 64, 3, 1, 1, (20, 28), 64), (64, 128, 1, 1, 0, (9, 9), 128), (64, 128, 1, 1, 0, (9, 9), 64), (256, 512, 3, 2, 1, (8, 8), 128),
     (48, 128, 3, 1, 1, (24, 24), 128), (128, 64, 1, 1, 0, (33, 17), 64), (1024, 256, 1, 1, 0, (7, 5), 128), (16, 64, 3, 2, 1, (33, 17), 64),
+    (64, 128, 1, 1, 0, (9, 9), "64x128"), (256, 512, 3, 2, 1, (8, 8), "64x64"), (1024, 256, 1, 1, 0, (7, 5), "64x128"), (32, 64, 3, 1, 1, (20, 28), "64x64"),
+    (48, 128, 3, 1, 1, (24, 24), "64x64"),
 ])
 def test_conv_split_bf16_matches_f32_kernel_tolerance(cin, cout, k, s, p, hw, bn_tile):
     """The OPT-IN split-bf16 kernel (conv_igemm_bf16x3.hip: three bf16 terms per fp32 operand, six bf16 MFMAs, fp32 accumulate) on the
@@ -91,7 +93,8 @@ def test_conv_split_bf16_matches_f32_kernel_tolerance(cin, cout, k, s, p, hw, bn
                 ops.conv2d([_nhwc(x)], wp, sc, sh, out, kh=k, kw=k, stride=s, pad=p, cout=cout, act=ops.ACT_RELU, res=_nhwc(res), split_bf16=True)
             finally:
                 del os.environ["CP_SPLIT_BF16_TILE"]
-            assert _lib.lib().cp_last_kernel().decode() == "igemm_bf16x3_kernel<128, %d>" % bn_tile
+            want = "igemm_bf16x3_kernel<%s>" % (bn_tile.replace("x", ", ") if isinstance(bn_tile, str) else "128, %d" % bn_tile)
+            assert _lib.lib().cp_last_kernel().decode() == want
         outs[mode] = out.permute(0, 3, 1, 2)
         _close(outs[mode], ref64.float())
     e32 = (outs["f32"].cpu().double() - ref64).abs().max().item()

@@ -465,6 +465,7 @@ def test_full_size_batch_invariance_and_scaling_property(monkeypatch):
     monkeypatch.setenv("CP_WINO_SPLITC", "0")
     monkeypatch.setenv("CP_WINO24_RULE", "32,16,1")       # round 4: F(2x4) vs F(2x2) is chosen by block count too -> no block floor
     monkeypatch.setenv("CP_CONV_SPLITK", "0")
+    monkeypatch.setenv("CP_SPLIT_BF16_MINBLOCKS", "0")    # round 5: (only when the suite runs with the opt-in CP_SPLIT_BF16=1) f32 vs split kernel by block count
     e4 = engine.Engine("dla_34", sd, 4, 512, 512)
     full = [t.clone() for t in e4(x)]
     del e4
@@ -479,6 +480,7 @@ def test_full_size_batch_invariance_and_scaling_property(monkeypatch):
     monkeypatch.setenv("CP_WINO_SPLITC", "1")
     monkeypatch.delenv("CP_WINO24_RULE")
     monkeypatch.delenv("CP_CONV_SPLITK")
+    monkeypatch.delenv("CP_SPLIT_BF16_MINBLOCKS")
     ef = engine.Engine("dla_34", sd, 4, 512, 512)
     assert any(l.fn == "cp_splitk_reduce_f32" for _, _, _, l in ef.launches)
     assert sum(l.fn == "cp_head3x3_1x1_f32" for _, _, _, l in ef.launches) == 6          # all six branches (round 3: hps / hm_hp too)
@@ -540,6 +542,7 @@ def test_full_size_b8_properties(arch, monkeypatch):
     monkeypatch.setenv("CP_WINO_SPLITC", "0")       # the split-C factor of a small-map launch depends on the batch: bit-for-bit batch
     monkeypatch.setenv("CP_WINO24_RULE", "32,16,1") # (and so does the F(2x4) / F(2x2) choice: no block floor)
     monkeypatch.setenv("CP_CONV_SPLITK", "0")       # (and the split-K factor of the generic kernel's small-M launches)
+    monkeypatch.setenv("CP_SPLIT_BF16_MINBLOCKS", "0")   # (and, when the suite runs with the opt-in CP_SPLIT_BF16=1, the f32-vs-split choice)
     sd = synth.make_state_dict(arch)                # invariance is a property of plans with the same per-output arithmetic
     x = synth.make_images(8, seed=123)
     e8 = engine.Engine(arch, sd, 8, 512, 512)

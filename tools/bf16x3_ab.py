@@ -37,7 +37,8 @@ def timeit(la, reps=5, iters=20):
     return best
 
 
-print("%-34s %-22s %-30s %-30s %s" % ("shape", "f32 MFMA (auto tile)", "split-bf16 <128,128>", "split-bf16 <128,64>", "max err vs fp64 (image 0): f32 | bf16x3"))
+MODES = ("f32", "128x128", "128x64", "64x128", "64x64")
+print("%-34s %-30s %s   %s" % ("shape", "f32 MFMA (auto tile)", "  ".join("%-22s" % ("sb<%s>" % m) for m in MODES[1:]), "max err vs fp64 (image 0): f32 | bf16x3 | rule"))
 ratios = []
 for name, B, H, Ci, Co, k, s in SHAPES:
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -48,28 +49,30 @@ for name, B, H, Ci, Co, k, s in SHAPES:
     Ho = (H + 2 * (k // 2) - k) // s + 1
     fl = 2.0 * B * Ho * Ho * Co * Ci * k * k
     ref = F.conv2d(x[:1].permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), None, s, k // 2).clamp_min(0).permute(0, 2, 3, 1)
-    cols, errs = [], []
-    for mode in ("f32", 128, 64):
+    cols, errs, tms = [], [], {}
+    for mode in MODES:
         out = torch.empty(B, Ho, Ho, Co, device="cuda")
         if mode == "f32":
             la = ops.conv2d_launch([x], wp, sc, sh, out, kh=k, kw=k, stride=s, pad=k // 2, cout=Co, act=1, split_bf16=False)
         else:
-            if wp.shape[0] % mode:
-                cols.append("-"); continue
-            os.environ["CP_SPLIT_BF16_TILE"] = str(mode)
+            if wp.shape[0] % int(mode.split("x")[1]):
+                cols.append("%-22s" % "-"); continue
+            os.environ["CP_SPLIT_BF16_TILE"] = mode
             la = ops.conv2d_launch([x], wp, sc, sh, out, kh=k, kw=k, stride=s, pad=k // 2, cout=Co, act=1, split_bf16=True)
             del os.environ["CP_SPLIT_BF16_TILE"]
         t = timeit(la)
-        kern = la.kernel.replace("igemm_conv_kernel", "ig").replace("igemm_bf16x3_kernel", "sb").replace(", 2, 2, 32, false", "")
-        cols.append("%.4f ms %6.1f TF %s" % (t, fl / t / 1e9, kern if mode == "f32" else ""))
-        if mode in ("f32", 128) or (mode == 64 and len(errs) < 2):
+        tms[mode] = t
+        kern = la.kernel.replace("igemm_conv_kernel", "ig").replace(", 2, 2, 32, false", "")
+        cols.append("%.4f ms %6.1f TF %s" % (t, fl / t / 1e9, kern) if mode == "f32" else "%-22s" % ("%.4f ms %5.1f TF" % (t, fl / t / 1e9)))
+        if mode == "f32" or len(errs) < 2:
             errs.append((out[:1].double().cpu() - ref).abs().max().item())
-        if mode == "f32":
-            t32 = t
-        else:
-            ratios.append((name, mode, t32 / t))
+        if mode != "f32":
+            ratios.append((name, mode, tms["f32"] / t))
     best = max([r for n, m, r in ratios if n == name] or [0.0])
     errs += [float("nan")] * (2 - len(errs))
-    print("%-34s %-22s %-30s %-30s %.2e | %.2e   best x%.2f" % (name, cols[0], cols[1], cols[2] if len(cols) > 2 else "-", errs[0], errs[1], best))
+    code = ops.split_bf16_tile(B * Ho * Ho, wp.shape[0], K=wp.shape[1])
+    rule = "f32" if code is None else "%dx%d" % ((code - 3000000) // 1000, code % 1000)
+    rr = 1.0 if rule == "f32" else tms["f32"] / tms.get(rule, tms["f32"])
+    print("%-34s %-30s %s   %.2e | %.2e   best x%.2f   rule -> %s x%.2f" % (name, cols[0], "  ".join(cols[1:]), errs[0], errs[1], best, rule, rr))
 go = max(r for n, m, r in ratios if n.startswith("GO/NO-GO")) if ratios else 0.0
 print("\nGO/NO-GO GEMM: split-bf16 / f32 MFMA speed ratio %.2f (kill criterion < 1.3): %s" % (go, "GO" if go >= 1.3 else "NO-GO"))
