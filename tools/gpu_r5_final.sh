@@ -14,5 +14,5 @@ r = l["roofline"]; print("dominant", r["kernel"], r["frac"], r["min_bound_frac"]
 for k, v in l["other_configs"].items():
     print(k, v.get("images_per_sec"), v.get("one_step_in_flight"), v.get("all_mfma_executed_frac"), v.get("error"))
 c = l["cpu_baseline"]; print("cpu", c["value"], c["cores"], c["sample"][:160])
-g = json.load(open("$OUT/bench_force_gather.json")); print("force-gather:", g["value"], g["backend"], g["ranks"], g["gather"])
+g = json.loads(open("$OUT/bench_force_gather.json").readline()); print("force-gather:", g["value"], g["backend"], g["ranks"], g["gather"])
 PY
