@@ -895,18 +895,6 @@ class EnginePipeline:
         joint.emission = joint.launches
         joint.graph, joint.capture_mode, joint.sched_cache = None, None, None
         joint.stream_plan = None
-        # CP_PIPE_POLICY=instance (experiment): instance k entirely on capture stream k % 2, launches interleaved in emission order --
-        # no cross-stream edges at all, each instance gives up its own branch parallelism; default: the critical-path scheduler over both
-        if os.environ.get("CP_PIPE_POLICY", "sched") == "instance":
-            per = [list(e.emission) for e in self.engines]
-            order, plan = [], []
-            for i in range(max(len(p) for p in per)):
-                for k, p in enumerate(per):
-                    if i < len(p):
-                        order.append(p[i])
-                        plan.append(k % 2)
-            joint.launches, joint.stream_plan = order, plan
-            joint.emission = joint.launches
         joint.use_graph = True
         joint.activation_bytes = sum(e.activation_bytes for e in self.engines)
         self.joint = joint
