@@ -323,7 +323,7 @@ def make_engines(arch, B, dev, depth, use_graph=True):
     from centerpose_amd import engine
     cc = {}
     engs = [make_engine(arch, B, dev, use_graph, cc, None) for _ in range(max(1, depth))]
-    pipe = engine.EnginePipeline(None, None, B, engines=engs) if depth > 1 and use_graph else None
+    pipe = engine.EnginePipeline.from_engines(engs) if depth > 1 and use_graph else None
     return engs, pipe
 
 

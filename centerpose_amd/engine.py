@@ -899,6 +899,17 @@ class EnginePipeline:
         joint.activation_bytes = sum(e.activation_bytes for e in self.engines)
         self.joint = joint
 
+    @classmethod
+    def from_engines(cls, engines):
+        """A pipeline over already built engines (same network / batch / size, built with `decode_k`, ideally sharing a `const_cache`)."""
+        engines = list(engines)
+        if not engines:
+            raise ValueError("at least one engine")
+        e0 = engines[0]
+        if any((e.arch, e.B, e.H, e.W, e.device) != (e0.arch, e0.B, e0.H, e0.W, e0.device) for e in engines):
+            raise ValueError("the instances of a pipeline are copies of ONE plan: same arch, batch, size and device")
+        return cls(e0.arch, None, e0.B, e0.H, e0.W, e0.device, depth=len(engines), engines=engines)
+
     @property
     def capture_mode(self):
         return self.joint.capture_mode
