@@ -70,6 +70,22 @@ def relaunch_under_torchrun(n):
     return subprocess.call(cmd, env=env)
 
 
+def cgroup_cpu_limit():
+    """CPUs' worth of time this container may use (cgroup v2 cpu.max / v1 cfs quota), or None: explains host layouts that get SLOWER
+    with more threads than the quota although more CPUs are visible."""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_model_name():
     try:
         for line in open("/proc/cpuinfo"):
@@ -192,6 +208,22 @@ def cpu_baseline(arch):
                 layouts.append({"processes": P, "threads_per_process": 16, "error": str(e)[:200]})
     r1 = best("res_50", 1, (8, 16, 32))
     r8 = best("res_50", 8, (16, 32))
+    # the credible host number (no DCN: oneDNN convolutions) on MANY cores: P worker processes x T pinned threads that
+    # together cover the physical cores the box has -- 4 x 32 and 8 x 16 on the 128-core bench boxes -- at batch 1 and batch 8 each
+    r_layouts = []
+    for P, T in ((4, 32), (8, 16)):
+        if P * T <= max(16, phys):
+            for Bp in (1, 8):
+                try:
+                    r_layouts.append(multiproc("res_50", Bp, P, T, secs=4.0))
+                except Exception as e:
+                    r_layouts.append({"processes": P, "threads_per_process": T, "batch_per_process": Bp, "error": str(e)[:200]})
+    r_all = [(r1["images_per_sec"], r1["threads"], "1 process, batch 1, %d torch threads" % r1["threads"]),
+             (r8["images_per_sec"], r8["threads"], "1 process, batch 8, %d torch threads" % r8["threads"])]
+    r_all += [(l["images_per_sec"], l["processes"] * l["threads_per_process"],
+               "%d processes x %d pinned threads, batch %d each" % (l["processes"], l["threads_per_process"], l["batch_per_process"]))
+              for l in r_layouts if "images_per_sec" in l]
+    r_top = max(r_all)
     cands = [(b1["images_per_sec"], b1["threads"], "1 process, batch 1, %d torch threads" % b1["threads"]),
              (b8["images_per_sec"], b8["threads"], "1 process, batch 8, %d torch threads" % b8["threads"])]
     cands += [(l["images_per_sec"], l["processes"] * l["threads_per_process"],
@@ -204,8 +236,11 @@ def cpu_baseline(arch):
                       " NOTE: the dla_34 host figure is bounded by the oracle's gather-based DCNv2 restatement (the reference has no "
                       "CPU DCN at all), not by what the host can do; res_50_b1 / res_50_b8 (no DCN, oneDNN convolutions) are the "
                       "credible host numbers." if arch.startswith("dla") else ""),
-            "cpu_model": cpu_model_name(), "logical_cpus": ncpu, "physical_cores": phys,
-            arch + "_b1": b1, arch + "_b8": b8, arch + "_multiprocess": layouts, "res_50_b1": r1, "res_50_b8": r8}
+            "cpu_model": cpu_model_name(), "logical_cpus": ncpu, "physical_cores": phys, "cgroup_cpu_limit": cgroup_cpu_limit(),
+            arch + "_b1": b1, arch + "_b8": b8, arch + "_multiprocess": layouts, "res_50_b1": r1, "res_50_b8": r8,
+            "res_50_multiprocess": r_layouts,
+            "res_50_best": {"images_per_sec": r_top[0], "cores": r_top[1], "layout": r_top[2],
+                            "note": "BASELINE.json configs[0]'s network on the host, best of every layout tried (threads actually used)"}}
 
 
 def roofline(eng, arch, B, wall_ms=None):
@@ -307,39 +342,52 @@ def roofline(eng, arch, B, wall_ms=None):
     return roof
 
 
-def make_engine(arch="dla_34", B=16, dev="cuda", use_graph=True, const_cache=None, sched_cache=None):
-    """THE timed configuration: seeded synthetic checkpoint, B x 3 x 512 x 512, the decode inside the engine's schedule
-    (forward + sigmoid + decode = ONE two-stream hipGraph replay per step).  tests/test_engine_hip.py::
-    test_timed_configuration_parity builds its engine through this function, so what is parity-tested is what is timed."""
-    from centerpose_amd import engine, synth
-    return engine.Engine(arch, synth.make_state_dict(arch), B, 512, 512, device=dev, use_graph=use_graph, decode_k=100,
-                         const_cache=const_cache, sched_cache=sched_cache)
+def make_detector(arch="dla_34", use_graph=True):
+    """THE timed configuration behind the reference's own entry point: `detector_factory['multi_pose'](cfg)` (tools/demo.py:47-49,
+    lib/detectors/multi_pose.py:24-60) on the experiment preset of `arch` with FLIP_TEST off (the batched path; the flip test is a
+    batch of exactly image + mirrored twin), the seeded synthetic checkpoint in the reference's key layout (cfg.SEED = 317, what
+    `BackBoneWithHead` starts from when no TEST.MODEL_PATH is given).  Everything bench.py times goes through
+    `MultiPoseDetector.process` / `MultiPoseDetector.process_stream` of this object."""
+    import contextlib
+    from centerpose_amd import config
+    from centerpose_amd.detector import detector_factory
+    cfg = config.get_cfg(arch, TEST__FLIP_TEST=False)
+    with contextlib.redirect_stdout(sys.stderr):             # ("Creating model..." -- stdout carries the ONE JSON line)
+        det = detector_factory["multi_pose"](cfg)
+    det.model.use_graph = use_graph
+    return det
 
 
-def make_engines(arch, B, dev, depth, use_graph=True):
-    """`depth` instances of THE timed configuration (own activations / static buffers each, packed constants shared) and, for
-    depth > 1, the engine.EnginePipeline that schedules their launch lists together and captures ONE hipGraph: one replay = `depth`
-    steps in flight.  -> (engines, pipeline or None)"""
-    from centerpose_amd import engine
-    cc = {}
-    engs = [make_engine(arch, B, dev, use_graph, cc, None) for _ in range(max(1, depth))]
-    pipe = engine.EnginePipeline.from_engines(engs) if depth > 1 and use_graph else None
-    return engs, pipe
+def make_engine(arch="dla_34", B=16, dev="cuda", use_graph=True, det=None):
+    """The compiled plan of THE timed configuration: B x 3 x 512 x 512, the decode inside the plan's schedule (forward + sigmoid +
+    decode = ONE two-stream hipGraph replay per step) -- the object `make_detector(arch).process(images)` runs, taken out of the
+    detector's model so that tests and the roofline pass can look inside.  tests/test_engine_hip.py::test_timed_configuration_parity
+    builds its engine (and, for the two-steps-in-flight arrangement, its pipeline) through this function and `make_detector`, so what
+    is parity-tested is what is timed."""
+    det = det if det is not None else make_detector(arch, use_graph)
+    return det.model.engine_for(B, 512, 512, decode_k=det.cfg.TEST.TOPK)
 
 
-def timed_replays(eng, pipe, steps, warmup):
-    """`steps` steps: with a pipeline, steps // depth joint replays (depth steps each) + the remainder as single replays of `eng`;
-    host clock around one device synchronisation.  -> seconds"""
+def make_batches(B, depth, seed=317):
+    """`depth` DIFFERENT synthetic image batches (host tensors): the steps in flight never see the same pixels."""
+    from centerpose_amd import synth
+    return [synth.make_images(B, seed=seed + 1000 * i) for i in range(max(1, depth))]
+
+
+def feed(batches, n):
+    for i in range(n):
+        yield batches[i % len(batches)]
+
+
+def timed_stream(det, batches, steps, warmup, depth):
+    """`steps` steps through the PRODUCT entry point -- `MultiPoseDetector.process_stream(batches, depth)` (depth 1:
+    `MultiPoseDetector.process` per batch) -- host clock around one device synchronisation; every step copies its batch into the
+    plan's static input and hands back a fresh `dets` (both inside the timing).  -> seconds"""
     import torch
-    D = pipe.depth if pipe is not None else 1
     def run(n):
-        for _ in range(n // D if pipe is not None else 0):
-            pipe.process_all()
-        for _ in range(n % D if pipe is not None else n):
-            eng.process(eng.input)
-    eng.process(eng.input)                                   # (captures happen outside the timing)
-    if pipe is not None:
-        pipe.process_all()
+        for _ in det.process_stream(feed(batches, n), depth=depth):
+            pass
+    run(2 * max(1, depth) + 1)                               # plan compilation, schedules, BOTH captures (joint + single): outside the timing
     run(warmup)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -361,30 +409,76 @@ def other_configs(dev, steps=20, warmup=5, depth=2):
     for key, arch, B, split in (("res_50_b8", "res_50", 8, False), ("hrnet_b8", "hrnet", 8, False), ("res_50_b8_split_bf16", "res_50", 8, True)):
         saved = ops.SPLIT_BF16
         try:
-            ops.SPLIT_BF16 = split
-            engs, pipe = make_engines(arch, B, dev, depth)
+            det = make_detector(arch)
+            ops.SPLIT_BF16 = split                                            # read when a plan is compiled
+            eng = make_engine(arch, B, det=det)
+            pipe = det.model.pipeline_for(B, 512, 512, det.cfg.TEST.TOPK, depth) if depth > 1 else None
             ops.SPLIT_BF16 = saved
-            eng = engs[0]
-            el1 = timed_replays(eng, None, steps, warmup)                     # one replay after the other (rounds 1-4)
-            el = timed_replays(eng, pipe, steps, warmup) if pipe is not None else el1
+            batches = [x.to(dev) for x in make_batches(B, depth)]
+            el1 = timed_stream(det, batches, steps, warmup, 1)                # one replay after the other (rounds 1-4)
+            el = timed_stream(det, batches, steps, warmup, depth) if depth > 1 else el1
             r = roofline(eng, arch, B, wall_ms=el1 / steps * 1e3)
             out[key] = {
                 "images_per_sec": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 3), "steps": steps, "steps_in_flight": depth,
                 "one_step_in_flight": {"images_per_sec": round(B * steps / el1, 1), "ms_per_step": round(el1 / steps * 1e3, 3)},
+                "entry_point": "MultiPoseDetector.process_stream(batches, depth=%d) / MultiPoseDetector.process" % depth,
                 "graph_capture": eng.capture_mode, "pipeline_graph_capture": pipe.capture_mode if pipe is not None else None, "end_to_end_tflops": round(eng.flops_per_image * B * steps / el / 1e12, 2),
+                "launches_per_step": len(eng.launches),
                 "all_mfma_executed_frac": r["all_mfma_kernels"]["executed_frac"],
                 "min_bound_frac": r["min_bound_frac"],
                 "dominant_kernel": r["kernel"], "dominant_frac": r["frac"], "dominant_time_share": r["time_share"],
                 "templates": r["templates"]}
             if split:
                 out[key]["mode"] = "CP_SPLIT_BF16=1 (opt-in, fp32-equivalent 3-term bf16 split on v_mfma_f32_32x32x16_bf16; NOT the metric's arithmetic path)"
-            del eng, engs, pipe
+            del eng, pipe, det, batches
             torch.cuda.empty_cache()
         except Exception as e:            # evidence, not the metric: a failure here must not take the bench line down
             out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         finally:
             ops.SPLIT_BF16 = saved
+    try:
+        out["run_latency_b1"] = run_latency("dla_34")
+    except Exception as e:
+        out["run_latency_b1"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     return out
+
+
+def run_latency(arch="dla_34", n=50, warm=5):
+    """The ONE quantity the reference publishes for itself (23 / 28 / 16 FPS for dla_34 / res_50 / hrnet, README.md:12-16,
+    measured through `BaseDetector.run`, lib/detectors/base_detector.py:79-140): a single 480x640 uint8 image through
+    `detector.run(image)` -- pre_process -> process -> post_process -> merge_outputs -- of the SHIPPED experiment configuration of
+    `arch` (dla_34: FLIP_TEST on = a batch of image + mirrored twin, FIX_RES off, soft-NMS on), every stage on the device, the
+    reference's own seven timers.  Median over `n` calls after `warm`.  Context for the published FPS (other hardware, trained
+    checkpoint, JPEG decode not included here), not the metric."""
+    import contextlib
+    import numpy as np
+    import torch
+    from centerpose_amd import config
+    from centerpose_amd.detector import detector_factory
+    cfg = config.get_cfg(arch)                                   # the experiment preset as shipped
+    with contextlib.redirect_stdout(sys.stderr):
+        det = detector_factory["multi_pose"](cfg)
+    img = (np.random.RandomState(0).rand(480, 640, 3) * 255).astype(np.uint8)
+    for _ in range(warm):
+        det.run(img)
+    keys = ("tot", "load", "pre", "net", "dec", "post", "merge")
+    rows, walls = {k: [] for k in keys}, []
+    for _ in range(n):
+        t0 = time.perf_counter()
+        r = det.run(img)
+        torch.cuda.synchronize()
+        walls.append((time.perf_counter() - t0) * 1e3)
+        for k in keys:
+            rows[k].append(r[k] * 1e3)
+    med = lambda v: sorted(v)[len(v) // 2]
+    wall = med(walls)
+    return {"arch": arch, "input": "one 480x640x3 uint8 image (host array), detector.run(image)", "calls": n,
+            "config": {"FLIP_TEST": bool(cfg.TEST.FLIP_TEST), "FIX_RES": bool(cfg.TEST.FIX_RES), "TEST_SCALES": list(cfg.TEST.TEST_SCALES),
+                       "NMS": bool(cfg.TEST.NMS), "network_batch": 2 if cfg.TEST.FLIP_TEST else 1},
+            "wall_ms_per_image_median": round(wall, 3), "fps": round(1e3 / wall, 1),
+            "stage_ms_median": {k: round(med(rows[k]), 3) for k in keys},
+            "reference_published_fps": {"dla_34": 23, "res_50": 28, "hrnet": 16}.get(arch),
+            "note": "reference FPS: README.md:12-16 (its own hardware, trained weights); here: synthetic weights, same stages and timers"}
 
 
 def main():
@@ -409,47 +503,40 @@ def main():
     dev = torch.device("cuda", local)
 
     B = args.batch
-    # the decode is part of the engine's schedule (decode_k): forward + sigmoid + decode = ONE hipGraph replay per step, the
-    # peak extraction overlapping the last head convolutions on the second capture stream
-    # Round 5: D = --in-flight instances of that plan (default 2), their launch lists scheduled TOGETHER on the two capture streams and
-    # captured into ONE hipGraph (engine.EnginePipeline): one replay = D steps in flight, the kernels of one step fill the launch gaps
-    # and the tails of the other's dependency chain.  Every step still is one batch of B images through the whole path, and all of the
-    # K timed steps complete inside the timed region (K // D joint replays + K % D single replays).  D = 1: rounds 1-4.
+    # Everything timed goes through the PRODUCT entry points: `MultiPoseDetector.process_stream(batches, depth=D)`
+    # -- the replacement of lib/detectors/multi_pose.py:29-60 over a stream of batches.  The decode is part of the plan's schedule:
+    # forward + sigmoid + decode = ONE hipGraph replay per step, the peak extraction overlapping the last head convolutions on the
+    # second capture stream.  D = --in-flight (default 2): D instances of that plan, their launch lists scheduled TOGETHER on the two
+    # capture streams and captured into ONE hipGraph (engine.EnginePipeline behind model.BackBoneWithHead.process_many): one replay
+    # = D steps in flight on D DIFFERENT batches, the kernels of one step fill the launch gaps and the chain tails of the other.  Every
+    # step still is one batch of B images through the whole path (its batch copied into the plan's static input, a fresh `dets`
+    # handed back: both inside the timing), and all of the K timed steps complete inside the timed region (K // D joint replays + K %
+    # D single ones).  D = 1: `MultiPoseDetector.process` per batch, what rounds 1-4 timed.
     D = max(1, args.in_flight) if not args.no_graph else 1
     lo, _ = cpd.shard_range(B * world, rank, world)
-    images = synth.make_images(B, seed=317 + lo).to(dev)      # this rank's shard, resident in HBM
-    engs, pipe = make_engines(args.arch, B, dev, D, use_graph=not args.no_graph)
-    eng = engs[0]
-    for e in engs:
-        e.input.copy_(images)
+    batches = [x.to(dev) for x in make_batches(B, D, seed=317 + lo)]      # this rank's shard(s), resident in HBM
+    det = make_detector(args.arch, use_graph=not args.no_graph)
+    eng = make_engine(args.arch, B, det=det)
+    pipe = det.model.pipeline_for(B, 512, 512, det.cfg.TEST.TOPK, D) if D > 1 else None
     gat = cpd.DetsGatherer(global_batch=B * world, time_waits=True, force=args.force_gather)
 
     def hand_over(dets):
-        """the step's detections: the all-gather is left running on the side stream and collected one step later"""
+        """the step's detections (a fresh tensor from the entry point): the all-gather is left running on the side stream and
+        collected one step later"""
         prev = gat.collect() if gat.pending else None
-        gat.submit(dets.clone())         # static buffer of the plan instance: the exchange / the caller get their own copy
+        gat.submit(dets)
         return prev
 
     def run_steps(n, marks=None):
-        """n steps: n // D joint replays (D steps each) + n % D single replays; one HIP event after every replay."""
-        done = 0
-        for _ in range(n // D if pipe is not None else 0):
-            for _, dets in pipe.process_all():
-                hand_over(dets)
-            done += D
-            if marks is not None:
-                marks.append((torch.cuda.Event(enable_timing=True), D))
-                marks[-1][0].record()
-        for _ in range(n - done):
-            _, dets = eng.process(eng.input)
+        """n steps through MultiPoseDetector.process_stream; one HIP event after every step's hand-over."""
+        for _, dets in det.process_stream(feed(batches, n), depth=D):
             hand_over(dets)
             if marks is not None:
-                marks.append((torch.cuda.Event(enable_timing=True), 1))
-                marks[-1][0].record()
+                marks.append(torch.cuda.Event(enable_timing=True))
+                marks[-1].record()
 
-    eng.process(eng.input)               # captures (and the measured schedules) outside the timing
-    if pipe is not None:
-        pipe.process_all()
+    run_steps(2 * D + 1)                 # plan compilation, measured schedules and BOTH captures (the joint graph and instance 0's
+                                         # own, which runs a last odd step) outside the timing
     run_steps(args.warmup)
     if gat.pending:
         gat.collect()
@@ -486,8 +573,8 @@ def main():
                        "timed_with": "HIP events around the compute stream's wait for the side-stream gather" if gat.time_waits
                                      else "not timed (host-staged gloo gather is synchronous)"}
         if args.gather_check:
-            _, last = eng.process(eng.input)
-            ok, _, msg = cpd.check_gathered(cpd.gather_dets(last.clone(), B * world, force=args.force_gather), last, B * world)
+            _, last = det.process(batches[0])
+            ok, _, msg = cpd.check_gathered(cpd.gather_dets(last, B * world, force=args.force_gather), last, B * world)
             gather_info["check"] = msg
             assert ok, msg
     assert out.shape == (B * world, 100, 56)
@@ -496,12 +583,18 @@ def main():
         ms_step = elapsed / args.steps * 1e3
         value = B * world * args.steps / elapsed
         per, last = [], start
-        for ev, nst in marks:                              # a joint replay completes D steps at once: its time is shared by them
-            per += [last.elapsed_time(ev) / nst] * nst
+        ngroups = args.steps // D if pipe is not None else 0
+        for g in range(ngroups):                           # a joint replay completes D steps at once: its time is shared by them
+            ev = marks[g * D + D - 1]
+            per += [last.elapsed_time(ev) / D] * D
+            last = ev
+        for ev in marks[ngroups * D:]:
+            per.append(last.elapsed_time(ev))
             last = ev
         per.sort()
         pct = lambda q: per[min(len(per) - 1, int(q * len(per)))]
-        line = {"metric": "images/sec end-to-end (backbone+decode), DLA-34 512x512", "value": round(value, 2),
+        arch_name = {"dla_34": "DLA-34", "res_50": "ResNet-50", "hrnet": "HRNet-W32"}.get(args.arch, args.arch)
+        line = {"metric": "images/sec end-to-end (backbone+decode), %s 512x512" % arch_name, "value": round(value, 2),
                 "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(ms_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "f32", "data": "synthetic",
@@ -509,12 +602,16 @@ def main():
                                        "decode%s" % (args.arch, B, ", RCCL all-gather of decoded poses (side stream)" if world > 1 else ""),
                            "global_batch": B * world, "parallelism": "dp%d" % world, "hipgraph": not args.no_graph,
                            "weights": "seeded synthetic checkpoint (reference key layout)",
-                           "steps_in_flight": D,
+                           "entry_point": "centerpose_amd.detector.MultiPoseDetector.process_stream(batches, depth=%d)" % D if D > 1 else
+                                          "centerpose_amd.detector.MultiPoseDetector.process(images)",
+                           "steps_in_flight": D, "images_per_replay": B * D,
+                           "batch_latency_ms": round(ms_step * D, 3),
                            "pipeline": ("%d instances of the compiled plan (own activations and static buffers, packed weights shared) whose "
                                         "launch lists are scheduled together on the two capture streams and captured into ONE hipGraph: one "
-                                        "replay = %d steps (each one batch of %d images through the whole path) whose kernels fill each "
-                                        "other's launch gaps and chain tails; `one_step_in_flight` = one step per replay, as timed in rounds "
-                                        "1-4" % (D, D, B)) if D > 1 else "one step per replay"},
+                                        "replay = %d steps on %d DIFFERENT batches (each one batch of %d images through the whole path, its "
+                                        "result available when the replay ends: latency = batch_latency_ms) whose kernels fill each other's "
+                                        "launch gaps and chain tails; `one_step_in_flight` = MultiPoseDetector.process per batch, one step "
+                                        "per replay, the arrangement rounds 1-4 timed" % (D, D, D, B)) if D > 1 else "one step per replay"},
                 "ranks": dist.get_world_size() if grouped else 1,
                 "backend": dist.get_backend() if grouped else None,
                 "rank_ms_per_step": {k: round(v, 3) for k, v in rank_ms.items()},
@@ -524,21 +621,26 @@ def main():
                 "step_ms": {"median": round(pct(0.5), 3), "p10": round(pct(0.1), 3), "p90": round(pct(0.9), 3),
                             "min": round(per[0], 3), "max": round(per[-1], 3),
                             "source": "HIP events per step on the launch stream" if D == 1 else
-                                      "HIP events per replay on the launch stream, a joint replay's time divided by its %d steps" % D},
+                                      "HIP events on the launch stream, a joint replay's time divided by its %d steps" % D},
                 "end_to_end_tflops": round(eng.flops_per_image * value / world / 1e12, 2),
                 "activation_mb": round(eng.activation_bytes / 1e6, 1)}
         if not args.no_profile:
             line["roofline"] = roofline(eng, args.arch, B, wall_ms=ms_step)
-            # DVFS (MI355X_MICROARCH.md: short bursts clock higher): the same step over >= 1000 replays AFTER the timed region
+            # DVFS (MI355X_MICROARCH.md: short bursts clock higher): the same steps over >= 1000 more AFTER the timed region
             n_sus = max(1000, args.steps)
-            sus = timed_replays(eng, pipe, n_sus, 0)
-            line["sustained"] = {"replays": n_sus, "seconds": round(sus, 3), "images_per_sec": round(B * n_sus / sus, 1),
+            sus = timed_stream(det, batches, n_sus, 0, D)
+            line["sustained"] = {"steps": n_sus, "seconds": round(sus, 3), "images_per_sec": round(B * n_sus / sus, 1),
                                  "ms_per_step": round(sus / n_sus * 1e3, 3), "steps_in_flight": D,
-                                 "note": "graph replays after the timed region, one host sync at the end (no gather, no clone)"}
-            # what rounds 1-4 timed: ONE instance, one replay after the other on the current stream (same kernels, same bits)
+                                 "note": "the same entry point after the timed region, one host sync at the end (no gather)"}
+            # what rounds 1-4 timed: MultiPoseDetector.process per batch, one replay after the other (same kernels, same bits)
             n_one = max(100, args.steps)
-            one = timed_replays(eng, None, n_one, 3)
-            line["one_step_in_flight"] = {"replays": n_one, "images_per_sec": round(B * n_one / one, 1), "ms_per_step": round(one / n_one * 1e3, 3)}
+            one = timed_stream(det, batches, n_one, 3, 1)
+            line["one_step_in_flight"] = {"steps": n_one, "images_per_sec": round(B * world * n_one / one, 1), "ms_per_step": round(one / n_one * 1e3, 3),
+                                          "entry_point": "centerpose_amd.detector.MultiPoseDetector.process(images)",
+                                          "note": "rank 0's own rate x ranks, measured after the timed region (no gather)" if world > 1 else
+                                                  "measured after the timed region"}
+            line["config"]["one_step_in_flight"] = line["one_step_in_flight"]          # (inside `config`: the driver's record keeps it)
+            line["roofline"]["one_step_in_flight_images_per_sec"] = line["one_step_in_flight"]["images_per_sec"]
             # ---- decode alone (latency-bound; reported as us/batch next to its HBM GB/s) ------------------
             hm, wh, hps, reg, hm_hp, hp_offset = eng.outputs
             for _ in range(3):
@@ -554,7 +656,7 @@ def main():
             line["decode"] = {"us_per_batch": round(dec_us, 1), "algorithmic_bytes": dec_bytes,
                               "gbps": round(dec_bytes / dec_us / 1e3, 1), "kernels": "nms_topk_kernel + pose_assign_kernel"}
         if world == 1 and not args.no_profile and not args.no_other_configs and args.arch == "dla_34":
-            line["other_configs"] = other_configs(dev, depth=D)
+            line["other_configs"] = other_configs(dev, depth=max(2, D))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.arch)
         print(json.dumps(line), flush=True)

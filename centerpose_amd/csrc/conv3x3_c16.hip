@@ -194,7 +194,7 @@ static int launch_c16(const ConvArgs& a, hipStream_t s)
     const long long cap = (long long)ncu * OCC;             // persistent: OCC resident blocks per CU walk the tiles
     const long long grid = ntiles < cap ? ntiles : cap;
     hipLaunchKernelGGL((conv3x3_c16_kernel<NT, S, TH, TW, OCC, TBW>), dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, tilesX, tilesY, (int)ntiles);
-    cp_note_kernel("conv3x3_c16_kernel<%d, %d, %d, %d>", NT, S, TH, TW);
+    cp_note_kernel("conv3x3_c16_kernel<%d, %d, %d, %d, %d, %d>", NT, S, TH, TW, OCC, TBW);      // as rocprofv3 prints the instantiation
     return 0;
 }
 

@@ -434,7 +434,7 @@ int cp_launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s)
     if (grid * dmax >= (1ll << 32)) { cp_set_error("conv3x3_winograd24: grid %lld too large", grid); return 1; }
     if (fast) hipLaunchKernelGGL(conv3x3_wino24_kernel<true>, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
     else hipLaunchKernelGGL(conv3x3_wino24_kernel<false>, dim3((unsigned)grid), dim3(IG_THREADS), smem, s, a, gd);
-    cp_note_kernel("conv3x3_wino24_kernel");
+    cp_note_kernel(fast ? "conv3x3_wino24_kernel<true>" : "conv3x3_wino24_kernel<false>");      // as rocprofv3 prints the instantiation
     return 0;
 }
 
@@ -477,7 +477,7 @@ int cp_launch_conv3x3_wino24_group(const ConvArgs* a, int n, hipStream_t s)
     }
     if (fast) hipLaunchKernelGGL(conv3x3_wino24_group_kernel<true>, dim3((unsigned)total), dim3(IG_THREADS), smem, s, g);
     else hipLaunchKernelGGL(conv3x3_wino24_group_kernel<false>, dim3((unsigned)total), dim3(IG_THREADS), smem, s, g);
-    cp_note_kernel("conv3x3_wino24_group_kernel");
+    cp_note_kernel(fast ? "conv3x3_wino24_group_kernel<true>" : "conv3x3_wino24_group_kernel<false>");
     return 0;
 }
 

@@ -17,7 +17,7 @@
 #include <cstdlib>
 #include "igemm.h"
 
-#define DCN_MAX_TAPS 9
+#define DCN_MAX_TAPS 121         // 11 x 11: the record rows live in LDS (20 B per (tap, pixel, deformable group)); the launcher checks the total
 typedef float dcn_v2 __attribute__((ext_vector_type(2)));
 
 // r = w.x * c00 + w.y * c01 + w.z * c10 + w.w * c11 on two channels (wxy = (w.x, w.y), wzw = (w.z, w.w)): one v_pk_mul_f32 and three
@@ -45,11 +45,13 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // records first, GEMM staging after; the NCHW epilogue reuses the whole region from the base
     // dg = deformable groups (dcn_v2_im2col_cuda.cu:153,162-164: input channel c samples with the offsets / mask of group
-    // c / (C / dg)): one record set per group, record index (g * DCN_MAX_TAPS + tap) * BM + pixel
+    // c / (C / dg)): one record set per group, record index (g * ntap + tap) * BM + pixel (ntap = kh * kw: any kernel size the
+    // LDS holds -- round 6; rounds 1-5 had a compile-time row count of 9)
     const int dg = a.dg;
+    const int ntap = a.kh * a.kw;
     float4* s_w = reinterpret_cast<float4*>(smem);                      // [dg][taps][BM] corner weights * mask
-    int* s_code = reinterpret_cast<int*>(s_w + dg * DCN_MAX_TAPS * BM); // [dg][taps][BM] base | dx<<29 | dy<<30
-    float* As0 = smem + dg * DCN_MAX_TAPS * BM * 5; // [2 buffers][A_FLOATS]
+    int* s_code = reinterpret_cast<int*>(s_w + dg * ntap * BM);         // [dg][taps][BM] base | dx<<29 | dy<<30
+    float* As0 = smem + dg * ntap * BM * 5;         // [2 buffers][A_FLOATS]
     float* Bs0 = As0 + 2 * T::A_FLOATS;             // [2 buffers][B_FLOATS]
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -63,7 +65,6 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     const int m0 = mt * BM, n0 = nt * BN;
     const int wm0 = (wid / WAVES_N) * T::WM, wn0 = (wid % WAVES_N) * T::WN;
     const int HoWo = a.Ho * a.Wo;
-    const int ntap = a.kh * a.kw;
     const int tap0 = sp * ntap / S, tap1 = (sp + 1) * ntap / S;       // this block's taps
     const int C = a.srcC[0], ld = a.srcLd[0];
     const float* __restrict__ x = a.src[0];
@@ -107,10 +108,10 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
             const float top = (t_ok ? hh : lh) * mv, bot = (dyb ? lh : 0.f) * mv;
             const float lft = l_ok ? hw : lw, rgt = dxb ? lw : 0.f;
             const int yl = min(max(h_low, 0), a.H - 1), xl = min(max(w_low, 0), a.W - 1);      // in range even for an invalid sample
-            s_w[(g * DCN_MAX_TAPS + t) * BM + pl] = make_float4(top * lft, top * rgt, bot * lft, bot * rgt);
+            s_w[(g * ntap + t) * BM + pl] = make_float4(top * lft, top * rgt, bot * lft, bot * rgt);
             // base = byte offset of the clamped top-left corner in 16-byte units (< 2^28: the launcher checks 32-bit byte offsets): the
             // multiply by the pixel stride is done HERE, once per record, not once per (tap, k-walk) in the main loop
-            s_code[(g * DCN_MAX_TAPS + t) * BM + pl] = (int)((unsigned)(bpix + yl * a.W + xl) * ld4) | ((dxb ? 1 : 0) << 29) | ((dyb ? 1 : 0) << 30);
+            s_code[(g * ntap + t) * BM + pl] = (int)((unsigned)(bpix + yl * a.W + xl) * ld4) | ((dxb ? 1 : 0) << 29) | ((dyb ? 1 : 0) << 30);
             kx += TS;
             while (kx >= a.kw) { kx -= a.kw; ++ky; }
         }
@@ -141,7 +142,7 @@ __global__ __launch_bounds__(IG_THREADS, 3) void dcn_igemm_kernel(const ConvArgs
     unsigned o00[ASL], o01[ASL], o10[ASL], o11[ASL];
     auto load_a = [&]() __attribute__((always_inline)) {
         if (cl == gnext) {                          // first k-step of a (tap, group): dg = 1 -> once per tap
-            grec = (cl == 0 ? 0 : grec + DCN_MAX_TAPS) ;
+            grec = (cl == 0 ? 0 : grec + ntap);
             gnext = cl + cpg;
 #pragma unroll
             for (int s = 0; s < ASL; ++s) {
@@ -235,8 +236,8 @@ static int launch_dcn(const ConvArgs& a, hipStream_t s)
     if (a.srcC[0] % IG_BK != 0) { cp_set_error("dcn: C=%d is not a multiple of %d", a.srcC[0], IG_BK); return 1; }
     if (a.ldw % BN != 0) { cp_set_error("dcn: ldw=%d is not a multiple of the N tile %d", a.ldw, BN); return 1; }
     if ((a.srcC[0] / a.dg) % IG_BK != 0) { cp_set_error("dcn: C / deformable_group = %d is not a multiple of %d", a.srcC[0] / a.dg, IG_BK); return 1; }
-    const int main_bytes = T::MAIN_BYTES + a.dg * DCN_MAX_TAPS * BM * 20;
-    if (main_bytes > 160 * 1024) { cp_set_error("dcn: deformable_group = %d needs %d B of LDS", a.dg, main_bytes); return 1; }
+    const int main_bytes = T::MAIN_BYTES + a.dg * a.kh * a.kw * BM * 20;
+    if (main_bytes > 160 * 1024) { cp_set_error("dcn: %d x %d taps x %d deformable group(s) need %d B of LDS for the sampling records", a.kh, a.kw, a.dg, main_bytes); return 1; }
     const int epi = a.outNCHW ? T::EPI_BYTES : T::EPV_BYTES;
     const int smem = epi > main_bytes ? epi : main_bytes;
     static CpLdsGuard guard;
@@ -270,7 +271,8 @@ extern "C" int cp_dcn_v2_f32(const cp_dcn_desc* d, const float* x, const float* 
                              const float* shift, float* out, void* stream)
 {
     CP_CHECK_ARG(d && x && om && w && scale && shift && out, "dcn_v2: null pointer");
-    CP_CHECK_ARG(d->kh * d->kw <= DCN_MAX_TAPS && d->kh * d->kw > 0, "dcn_v2: at most %d taps", DCN_MAX_TAPS);
+    CP_CHECK_ARG(d->kh > 0 && d->kw > 0 && d->kh * d->kw <= DCN_MAX_TAPS, "dcn_v2: 1..%d taps (kh=%d kw=%d)", DCN_MAX_TAPS, d->kh, d->kw);
+    CP_CHECK_ARG(d->sy > 0 && d->sx > 0 && d->dily > 0 && d->dilx > 0 && d->py >= 0 && d->px >= 0, "dcn_v2: stride / dilation > 0, pad >= 0");
     CP_CHECK_ARG(d->C % 16 == 0 && d->srcLd % 4 == 0 && d->srcLd >= d->C, "dcn_v2: C%%16==0, ld%%4==0 required");
     CP_CHECK_ARG(d->K == d->kh * d->kw * d->C, "dcn_v2: K=%d != kh*kw*C", d->K);
     CP_CHECK_ARG(d->ldw % 16 == 0 && d->ldw >= d->Cout, "dcn_v2: ldw=%d Cout=%d", d->ldw, d->Cout);

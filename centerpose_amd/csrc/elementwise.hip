@@ -7,6 +7,7 @@
 //   depthwise conv + BN + act       MobileNetV3 Block.conv2 / ShuffleNetV2 banch*  mobilenetv3.py:119-121, shufflenetv2_dcn.py:67-88
 //   squeeze-excite                  SeModule: global average pool, x * se(x) (+ shortcut)  mobilenetv3.py:99-113,141-143
 //   channel shuffle of a concat     ShuffleNetV2 InvertedResidual.forward            shufflenetv2_dcn.py:28-42,94-104
+#include <cstdlib>
 #include "common.h"
 
 #define EW_THREADS 256
@@ -72,8 +73,10 @@ extern "C" int cp_maxpool2d_nhwc_f32(const float* in, int inLd, float* out, int 
 }
 
 // out[b,oy,ox,c] = add[b,oy,ox,c] + sum_{ky,kx} in[b,iy,ix,c] * w[(ky*k+kx)][c],  oy = iy*f - p + ky
+// (`add` and `out` are NOT __restrict__: the engine may pass the same storage for both -- every thread reads exactly the `add`
+// elements it then writes, so in-place is well defined)
 __global__ void dw_deconv_add_kernel(const float* __restrict__ in, int inLd, const float* __restrict__ w,
-                                     const float* __restrict__ add, int addLd, float* __restrict__ out, int outLd, EwRow r,
+                                     const float* add, int addLd, float* out, int outLd, EwRow r,
                                      int H, int W, int f, int p)
 {
     const int k = 2 * f, Ho = H * f, Wo = W * f, C = r.C4 * 4;
@@ -116,7 +119,7 @@ __global__ void dw_deconv_add_kernel(const float* __restrict__ in, int inLd, con
 // being the limit).  Same taps in the same order per output as the generic kernel (ty, tx = 0, 1: ky = ry + 2 ty, kx = rx + 2 tx), out-of-range
 // taps contribute fma(0, w, acc) = acc: bit-identical for finite weights.
 __global__ __launch_bounds__(EW_THREADS) void dw_deconv2_add_kernel(const float* __restrict__ in, int inLd, const float* __restrict__ w,
-                                                                   const float* __restrict__ add, int addLd, float* __restrict__ out,
+                                                                   const float* add, int addLd, float* out,
                                                                    int outLd, EwRow r, int H, int W)
 {
     const int C = r.C4 * 4, Wo = 2 * W;
@@ -177,7 +180,10 @@ extern "C" int cp_dw_deconv_add_nhwc_f32(const float* in, int inLd, const float*
                  "dw_deconv_add: C, ld must be multiples of 4");
     CP_CHECK_ARG(f >= 1, "dw_deconv_add: f=%d", f);
     CP_CHECK_ARG((long long)W * f * (C / 4) * (C / 4) < (1ll << 32) && (long long)B * H * f < (1ll << 31), "dw_deconv_add: row too large");
-    if (f == 2 && (long long)W * (C / 4) * (C / 4) < (1ll << 32)) {
+    // CP_DWDECONV2=0: the generic kernel for f = 2 as well (A/B switch: tests compare the two bit for bit; read per call -- launches
+    // are recorded once per plan, not per step)
+    const char* sw = getenv("CP_DWDECONV2");
+    if (f == 2 && !(sw && sw[0] == '0') && (long long)W * (C / 4) * (C / 4) < (1ll << 32)) {
         const EwRow r2 = ew_row(B * H, W, C / 4);
         hipLaunchKernelGGL(dw_deconv2_add_kernel, ew_row_grid(r2), dim3(EW_THREADS), 0, (hipStream_t)stream, in, inLd, w, add, addLd, out,
                            outLd, r2, H, W);

@@ -77,11 +77,11 @@ at::Tensor dcn_v2_forward(const at::Tensor& input, const at::Tensor& weight, con
     TORCH_CHECK(weight.size(1) == C, "Input shape and kernel channels wont match: (", C, " vs ", weight.size(1), ").");   // :80-81
     TORCH_CHECK(weight.size(2) == kernel_h && weight.size(3) == kernel_w, "Input shape and kernel shape wont match: (", kernel_h,
                 " x ", kernel_w, " vs ", weight.size(2), " x ", weight.size(3), ").");                                   // :77-78
-    TORCH_CHECK(stride_h == stride_w && pad_h == pad_w && dilation_h == dilation_w, "square stride / pad / dilation only");
+    TORCH_CHECK(stride_h > 0 && stride_w > 0 && dilation_h > 0 && dilation_w > 0 && pad_h >= 0 && pad_w >= 0,
+                "stride / dilation must be positive, pad non-negative");      // independent per axis, as dcn_v2_cuda.cu:43-57,84-87
     const int dg = deformable_group;
     TORCH_CHECK(dg >= 1 && C % dg == 0, "channels (", C, ") must be divisible by deformable_group (", dg, ")");
     const int kk = kernel_h * kernel_w;
-    TORCH_CHECK(kk <= 9, "at most 9 taps");
     const int Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) / stride_h + 1;
     const int Wo = (W + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) / stride_w + 1;
     // dcn_v2_im2col_cuda.cu:162-164: group g's offsets are channels g*2*kk .., its masks channels g*kk ..

@@ -58,11 +58,11 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
     _check(Cw == C, "Input shape and kernel channels wont match: (%d vs %d)." % (C, Cw))       # :80-81
     _check(kh_ == kernel_h and kw_ == kernel_w, "Input shape and kernel shape wont match: (%d x %d vs %d x %d)."
            % (kernel_h, kernel_w, kh_, kw_))                                                    # :77-78
-    _check(stride_h == stride_w and pad_h == pad_w and dilation_h == dilation_w, "square stride/pad/dilation only")
+    _check(stride_h > 0 and stride_w > 0 and dilation_h > 0 and dilation_w > 0 and pad_h >= 0 and pad_w >= 0,
+           "stride / dilation must be positive, pad non-negative")       # independent per axis, as dcn_v2_cuda.cu:43-57,84-87
     dg = int(deformable_group)
     _check(dg >= 1 and C % dg == 0, "channels (%d) must be divisible by deformable_group (%d)" % (C, dg))
     kk = kernel_h * kernel_w
-    _check(kk <= 9, "at most 9 taps")
     Ho = (H + 2 * pad_h - (dilation_h * (kernel_h - 1) + 1)) // stride_h + 1
     Wo = (W + 2 * pad_w - (dilation_w * (kernel_w - 1) + 1)) // stride_w + 1
     # dcn_v2_im2col_cuda.cu:162-164: group g's offsets are channels g*2*kk .. and its masks channels g*kk ..
@@ -81,7 +81,7 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
     ops.nchw_to_nhwc(mask.contiguous(), om, 2 * dg * kk)
     wp, sc, sh = _packed_weights(weight, bias, dg)
     out = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=input.device)
-    ops.dcn_v2(x, om, wp, sc, sh, out, cout=Co, kh=kernel_h, kw=kernel_w, stride=stride_h, pad=pad_h, dil=dilation_h,
+    ops.dcn_v2(x, om, wp, sc, sh, out, cout=Co, kh=kernel_h, kw=kernel_w, stride=(stride_h, stride_w), pad=(pad_h, pad_w), dil=(dilation_h, dilation_w),
                om_sigmoid=False, out_nchw=True, dg=dg)
     return out
 

@@ -202,11 +202,31 @@ class MultiPoseDetector(BaseDetector):
         _lib.check(rc, "cp_flip_merge_f32")
         return out
 
+    def _one_replay_path(self):
+        """forward + decode can be ONE graph replay: nothing to do between them (no flip merge, no head gated off)."""
+        loss = self.cfg.LOSS
+        return (not self.cfg.TEST.FLIP_TEST and loss.REG_OFFSET and loss.HM_HP and loss.REG_HP_OFFSET and not loss.MSE_LOSS
+                and hasattr(self.model, "process"))
+
+    def process_stream(self, batches, depth=2):
+        """`process` over an iterable of image batches with `depth` steps in flight (model.BackBoneWithHead.process_many): a
+        generator of `(outputs, dets)` per batch, in order, each bit-identical to `process(batch)`.  Two consecutive batches are
+        captured into one hipGraph so that one step's kernels fill the other's launch gaps: throughput up, a batch's result
+        available only with its group (latency ~ depth x).  Configurations that need host logic between forward and decode
+        (FLIP_TEST, a head gated off by cfg.LOSS) run batch by batch through `process`.  The batched-throughput entry point of
+        BASELINE.json's metric; the reference has one image at a time (multi_pose.py:29-60, base_detector.py:79-140)."""
+        if self._one_replay_path() and hasattr(self.model, "process_many"):
+            # (no torch.no_grad() around the yields: a grad mode entered inside a generator leaks into the consumer between
+            # yields; nothing on this path records autograd history anyway -- raw HIP launches and a clone of a plain tensor)
+            for r in self.model.process_many(batches, self.cfg.TEST.TOPK, depth):
+                yield r
+            return
+        for images in batches:
+            yield self.process(images)
+
     def process(self, images, return_time=False):
         """multi_pose.py:29-60.  images: float32 NCHW, mean/std-normalised, on the HIP device."""
-        loss = self.cfg.LOSS
-        if (not return_time and not self.cfg.TEST.FLIP_TEST and loss.REG_OFFSET and loss.HM_HP and loss.REG_HP_OFFSET
-                and not loss.MSE_LOSS and hasattr(self.model, "process")):
+        if not return_time and self._one_replay_path():
             # no stage timing asked for and nothing to do between forward and decode: both in ONE graph replay (the peak
             # extraction overlaps the last head convolutions).  `run()` keeps the two-stage form for its 'net' / 'dec' timers.
             # `dets` is a fresh tensor on both paths (the reference returns one); `outputs` are the plan's static buffers.

@@ -13,25 +13,34 @@ import torch.distributed as dist
 def init_from_env(backend=None, force=False):
     """Initialise torch.distributed from torchrun's env (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_*).
     Returns (rank, world_size, local_rank); a no-op single-process answer when WORLD_SIZE is unset -- unless `force`:
-    then a process group of world size 1 is created all the same (rendezvous on a free 127.0.0.1 port), so that the
+    then a process group of world size 1 is created all the same (rendezvous through a private file store), so that the
     collective of `DetsGatherer(force=True)` really goes through RCCL on a one-GPU box."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world == 1 and not force:
         return 0, 1, 0
-    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    solo = force and world == 1 and "RANK" not in os.environ        # the forced group of ONE rank, no launcher around it
+    # under a launcher RANK is mandatory: WORLD_SIZE > 1 without it must fail here, not make every process rank 0 and hang the
+    # rendezvous (ADVICE r5)
+    rank = 0 if solo else int(os.environ["RANK"])
+    local = int(os.environ.get("LOCAL_RANK", "0"))
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:            # (only the forced single-process group gets here without a launcher)
-            import socket
-            with socket.socket() as s:
-                s.bind(("127.0.0.1", 0))
-                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend is None:
             backend = os.environ.get("CP_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local % max(1, torch.cuda.device_count()))
-        dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
+        if solo and "MASTER_PORT" not in os.environ:
+            # no TCP rendezvous for one process: a private file store (a pre-probed free port can be taken by someone else between the
+            # probe and the bind)
+            import tempfile
+            import uuid
+            path = os.path.join(tempfile.gettempdir(), "cp_pg_%d_%s" % (os.getpid(), uuid.uuid4().hex))
+            dist.init_process_group(backend=backend, init_method="file://" + path, world_size=1, rank=0)
+        else:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if "MASTER_PORT" not in os.environ:
+                raise KeyError("MASTER_PORT (torch.distributed.run / torchrun sets it; bench.py --gpus N launches itself under one)")
+            dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
     return rank, world, local
 
 

@@ -428,7 +428,8 @@ class PlanBuilder(nets.Graph):
         head's 1x1 right after its 3x3 on the same (B*H*W*hc*4 B = 268 MB at B=16) buffer keeps the
         intermediate resident in the 256 MiB Infinity Cache instead of streaming 1.6 GB through HBM."""
         H, W = feat.H, feat.W
-        per_head = self.B * H * W * hc * 4 <= 300 * (1 << 20) and hc >= 64
+        # (a batch-dependent rule like the block-count ones: evaluated at batch 1 under CP_BATCH_INVARIANT=1, ADVICE r5)
+        per_head = ops.rule_batch(self.B) * H * W * hc * 4 <= 300 * (1 << 20) and hc >= 64
         ft = feat.t
         outs = []
         if per_head:

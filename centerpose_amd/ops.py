@@ -457,6 +457,10 @@ def dcn_v2(x, om, wp, scale, shift, out, **kw):
     return out
 
 
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
 def dcn_v2_launch(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, pad=1, dil=1, om_sigmoid=True,
                   act=ACT_NONE, out_nchw=False, tile=0, ksplit=0, dg=1):
     """Fused DCNv2: x NHWC [B,H,W,C]; om NHWC [B,Ho,Wo,>=3*dg*kh*kw] (per group the dy,dx pairs; then per group the masks).
@@ -465,11 +469,12 @@ def dcn_v2_launch(x, om, wp, scale, shift, out, *, cout, kh=3, kw=3, stride=1, p
     shift = zeros, act none, cout = ldw) and `splitk_reduce_launch` finishes the layer."""
     B, H, W, C = x.shape
     d = DcnDesc()
-    Ho = (H + 2 * pad - (dil * (kh - 1) + 1)) // stride + 1
-    Wo = (W + 2 * pad - (dil * (kw - 1) + 1)) // stride + 1
+    (sy, sx), (py, px), (dy, dx) = _pair(stride), _pair(pad), _pair(dil)        # int or (h, w): dcn_v2_cuda.cu:43-57 takes both axes
+    Ho = (H + 2 * py - (dy * (kh - 1) + 1)) // sy + 1
+    Wo = (W + 2 * px - (dx * (kw - 1) + 1)) // sx + 1
     assert om.shape[:3] == (B, Ho, Wo)
     d.B, d.H, d.W, d.C, d.srcLd, d.Ho, d.Wo = B, H, W, C, _ld(x), Ho, Wo
-    d.kh, d.kw, d.sy, d.sx, d.py, d.px, d.dily, d.dilx = kh, kw, stride, stride, pad, pad, dil, dil
+    d.kh, d.kw, d.sy, d.sx, d.py, d.px, d.dily, d.dilx = kh, kw, sy, sx, py, px, dy, dx
     d.K, d.ldw, d.Cout = wp.shape[1], wp.shape[0], cout
     d.omLd, d.omSigmoid = _ld(om), 1 if om_sigmoid else 0
     d.outNCHW = 1 if out_nchw else 0

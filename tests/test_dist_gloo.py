@@ -6,6 +6,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -146,3 +147,20 @@ def test_shard_range_covers_batch():
             spans = [cpd.shard_range(gb, r, w) for r in range(w)]
             assert spans[0][0] == 0 and spans[-1][1] == gb
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+
+
+def test_world_above_one_without_rank_fails_instead_of_hanging(monkeypatch):
+    """ADVICE r5: WORLD_SIZE > 1 with no RANK must raise at once (every process silently becoming rank 0 hangs the rendezvous);
+    the RANK / MASTER_PORT defaults belong to the forced single-process group only."""
+    from centerpose_amd import dist as cpd
+    for k in ("RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    with pytest.raises(KeyError):
+        cpd.init_from_env("gloo")
+    with pytest.raises(KeyError):
+        cpd.init_from_env("gloo", force=True)
+    monkeypatch.setenv("RANK", "1")
+    with pytest.raises(KeyError, match="MASTER_PORT"):
+        cpd.init_from_env("gloo")
+    assert not dist.is_initialized()

@@ -657,6 +657,66 @@ def test_timed_configuration_parity(arch, B):
                   sorted(set(kernels) ^ set(timed)))
 
 
+def test_timed_configuration_parity_two_steps_in_flight():
+    """THE arrangement bench.py's headline times, at its own size and through the PRODUCT entry point:
+    `bench.make_detector("dla_34")` -> `MultiPoseDetector.process_stream(batches, depth=2)` at B = 16, 512 x 512 -- two plan
+    instances (2 x 1.84 GB of activations), ~190 launches scheduled jointly on the two capture streams, ONE hipGraph per two steps.
+    Replaces lib/detectors/multi_pose.py:29-60 over a stream of batches.
+    (a) every step's six maps and `dets` are torch.equal to `MultiPoseDetector.process` of the same batch (single plan, one step per
+        replay) -- four steps = two joint replays on two DIFFERENT batches, so the second replay reproduces the first;
+    (b) the second instance (the one no single-plan test ever ran): images 0 / 7 / 15 within the 1e-3 bar of the CPU oracle network,
+        `dets` of all 16 images == the oracle decode of the instance's own maps;
+    (c) the joint graph was captured on two streams and runs exactly the single plan's kernel instantiations, twice;
+    (d) `dets` are fresh tensors (not the plans' static buffers) and survive the next replay."""
+    import sys
+    from centerpose_amd import synth
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    B, D = 16, 2
+    det = bench.make_detector("dla_34")
+    host = bench.make_batches(B, D)
+    assert not torch.equal(host[0], host[1])
+    batches = [x.cuda() for x in host]
+    want = []
+    for x in batches:                                                                  # one step per replay: MultiPoseDetector.process
+        outs, dets = det.process(x)
+        want.append([t.clone() for t in outs] + [dets.clone()])
+    torch.cuda.synchronize()
+    got, kept = [], []
+    for outs, dets in det.process_stream(bench.feed(batches, 2 * D), depth=D):
+        got.append([t.clone() for t in outs] + [dets.clone()])
+        kept.append(dets)
+    torch.cuda.synchronize()
+    assert len(got) == 2 * D
+    for i, g in enumerate(got):                                                        # (a)
+        for n, a, b in zip(("hm", "wh", "hps", "reg", "hm_hp", "hp_offset", "dets"), g, want[i % D]):
+            assert torch.equal(a, b), "step %d %s differs from the one-step-per-replay result" % (i, n)
+    eng = bench.make_engine("dla_34", B, det=det)
+    pipe = det.model.pipeline_for(B, 512, 512, det.cfg.TEST.TOPK, D)
+    assert pipe.engines[0] is eng and pipe.capture_mode == "2-stream" and eng.capture_mode == "2-stream"      # (c)
+    statics = {e.dets.data_ptr() for e in pipe.engines}
+    assert len({k.data_ptr() for k in kept}) == 2 * D and not ({k.data_ptr() for k in kept} & statics)         # (d)
+    assert all(torch.equal(k, w[6]) for k, w in zip(kept, want + want))
+    kern = lambda launches: sorted(l.kernel or l.fn for _, _, _, l in launches)
+    assert kern(pipe.joint.launches) == sorted(kern(eng.launches) * D)
+    o = [t.cpu().numpy() for t in got[1][:6]]                                          # (b): step 1 ran on instance 1
+    dec = decode_np.multi_pose_decode(o[0], o[1], o[2], o[3], o[4], o[5], K=100)
+    assert np.array_equal(got[1][6].cpu().numpy(), dec)
+    sd = synth.make_state_dict("dla_34")
+    worst = {}
+    for i in (0, B // 2 - 1, B - 1):
+        refs = nets_torch.forward("dla_34", sd, host[1][i:i + 1])
+        for n, t, r in zip(("hm", "wh", "hps", "reg", "hm_hp", "hp_offset"), got[1], refs):
+            t, r = t[i:i + 1].cpu().double(), r.double()
+            if n in ("hm", "hm_hp"):
+                r = torch.sigmoid(r)
+            tol = 1e-3 if n in ("hm", "hm_hp", "reg", "hp_offset") else 1e-3 * r.abs().max().item()
+            err = (t - r).abs().max().item()
+            worst[n] = max(worst.get(n, 0.0), err / tol)
+            assert err <= tol, "instance 1 image %d %s: max err %.3e > %.3e" % (i, n, err, tol)
+    print("dla_34 B=16 two steps in flight, instance 1: worst error / tolerance per head: %s" % {k: round(v, 4) for k, v in worst.items()})
+
+
 @pytest.mark.parametrize("arch,depth", [("dla_34", 2), ("hrnet", 3)])
 def test_steps_in_flight_same_bits_as_one_after_the_other(arch, depth):
     """engine.EnginePipeline (what bench.py times since round 5: `depth` plan instances whose launch lists are scheduled TOGETHER and

@@ -359,3 +359,63 @@ def test_resdcn_checkpoint_keys_are_the_standalone_models():
     ispec, _ = nets.param_spec("resdcn_18", internal=True)
     assert set(inner) == set(ispec) and "backbone_model.conv1.weight" in inner and "head_model.hm.0.weight" in inner
     assert nets.internal_key("dla_34", "backbone_model.base.level0.0.weight") == "backbone_model.base.level0.0.weight"
+
+
+def test_process_many_groups_batches_in_order_and_falls_back(monkeypatch):
+    """model.BackBoneWithHead.process_many / detector.MultiPoseDetector.process_stream (the steps-in-flight entry points),
+    host logic only: batches are taken `depth` at a time IN ORDER; a full group of equal shapes goes through ONE joint replay
+    (`pipeline_for(...).process_all(group)`) and yields one fresh `dets` per batch; a short last group, a group of mixed shapes
+    (FIX_RES = false) and depth <= 1 go through `process`, one call per batch; a configuration that needs host logic between forward
+    and decode (FLIP_TEST) never reaches the pipeline.  Device code is replaced by recording stand-ins: no GPU here."""
+    from centerpose_amd import config, detector, model
+    cfg = config.get_cfg("res_50", TEST__FLIP_TEST=False)
+    m = model.create_model(cfg.MODEL.NAME, cfg.MODEL.HEAD_CONV, cfg)
+    calls = []
+
+    class FakePipe:
+        def __init__(self, key):
+            self.key = key
+
+        def process_all(self, group):
+            calls.append(("joint", self.key, [int(x[0, 0, 0, 0]) for x in group]))
+            return [(["outs%d" % int(x[0, 0, 0, 0])], torch.full((1, 2), float(x[0, 0, 0, 0]))) for x in group]
+
+    def fake_process(x, K=100):
+        calls.append(("single", tuple(x.shape), int(x[0, 0, 0, 0])))
+        return ["outs%d" % int(x[0, 0, 0, 0])], torch.full((1, 2), float(x[0, 0, 0, 0]))
+
+    monkeypatch.setattr(m, "pipeline_for", lambda B, H, W, K, depth: FakePipe((B, H, W, K, depth)))
+    monkeypatch.setattr(m, "process", fake_process)
+    mk = lambda i, h=8: torch.full((2, 3, h, 8), float(i))
+
+    def consumed():                                   # the generator must pull only `depth` batches ahead of what it has yielded
+        for i in range(5):
+            pulled.append(i)
+            yield mk(i)
+    pulled = []
+    gen = m.process_many(consumed(), K=7, depth=2)
+    first = next(gen)
+    assert pulled == [0, 1] and first[0] == ["outs0"] and float(first[1][0, 0]) == 0.0
+    rest = list(gen)
+    assert [o[0] for o, _ in [first] + rest] == ["outs%d" % i for i in range(5)]
+    assert calls == [("joint", (2, 8, 8, 7, 2), [0, 1]), ("joint", (2, 8, 8, 7, 2), [2, 3]), ("single", (2, 3, 8, 8), 4)]
+    # mixed shapes inside a group -> singles for that group only; depth 3; depth 1
+    calls.clear()
+    got = list(m.process_many([mk(0), mk(1, 16), mk(2), mk(3)], depth=2))
+    assert [c[0] for c in calls] == ["single", "single", "joint"] and len(got) == 4
+    calls.clear()
+    list(m.process_many([mk(i) for i in range(7)], depth=3))
+    assert [c[0] for c in calls] == ["joint", "joint", "single"] and calls[0][2] == [0, 1, 2]
+    calls.clear()
+    list(m.process_many([mk(i) for i in range(3)], depth=1))
+    assert [c[0] for c in calls] == ["single"] * 3
+    assert list(m.process_many([], depth=2)) == []
+    # the detector: FLIP_TEST off -> the model's stream; FLIP_TEST on -> process() per batch
+    det = object.__new__(detector.MultiPoseDetector)
+    det.cfg, det.model = cfg, m
+    calls.clear()
+    assert len(list(det.process_stream([mk(0), mk(1)], depth=2))) == 2 and calls[0][0] == "joint"
+    det.cfg = config.get_cfg("res_50", TEST__FLIP_TEST=True)
+    seen = []
+    monkeypatch.setattr(detector.MultiPoseDetector, "process", lambda self, images, return_time=False: seen.append(int(images[0, 0, 0, 0])) or ("o", "d"))
+    assert list(det.process_stream([mk(5), mk(6)], depth=2)) == [("o", "d")] * 2 and seen == [5, 6]

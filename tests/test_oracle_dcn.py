@@ -44,6 +44,10 @@ CASES = [
     dict(seed=4, B=1, C=4, H=13, W=9, Co=3, dh=2, dw=2, ph=2, pw=2),
     dict(seed=5, B=1, C=3, H=7, W=8, Co=2, kh=1, kw=1, ph=0, pw=0),
     dict(seed=6, B=2, C=6, H=5, W=6, Co=4, off_sigma=0.3, far=0.0),
+    # round 6: the rest of dcn_v2_forward's argument space (dcn_v2_cuda.cu:43-57: every parameter per axis, any kernel size)
+    dict(seed=7, B=1, C=4, H=12, W=15, Co=3, sh=2, sw=1, ph=1, pw=2, dh=1, dw=2),
+    dict(seed=8, B=1, C=3, H=11, W=9, Co=2, kh=5, kw=5, ph=2, pw=2),
+    dict(seed=9, B=2, C=4, H=10, W=13, Co=3, kh=3, kw=5, sh=2, sw=2, ph=3, pw=1, dh=2, dw=1),
 ]
 
 

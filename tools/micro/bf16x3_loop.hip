@@ -8,6 +8,12 @@
 //   MODE 3  + the k-step's global loads (2 float4 A + 3 uint4 pre-split B per thread, L2-resident)
 //   MODE 4  as 3, software-pipelined: the split of the NEXT k-step's activations (loaded one iteration earlier) is interleaved with
 //           the MFMAs (one split2 pair per output tile), the loads for the k-step after that are issued behind the LDS writes
+//   MODE 6  (round 6, VERDICT r5 #3 "stage C" go / no-go) BOTH operands PRE-SPLIT in global memory ([row][k-step][3 terms][16 bf16]: the
+//           producer's epilogue would write the activation that way, 6 B per element) and staged with global_load_lds_dwordx4
+//           (LDS-DMA): no v_cvt_pk, no ds_write.  LDS image [term][row][32 B], the two 16-byte halves of a row XOR-swizzled on the
+//           SOURCE address (the DMA destination is lane-linear) so that the ds_read_b128 fragment reads stay conflict-free; two LDS
+//           buffers, the next k-step's 6 DMAs per thread issued in front of the MFMA block, one __syncthreads() (vmcnt(0)) per k-step.
+//           kglds<.., 2>: two k-steps (K = 32) per barrier.  go: >= 330 TF fp32-equivalent.
 // The last line is the f32 MFMA loop of mfma_peak.hip (LDS-fed, same process) = "the fp32 loop" of the kill criterion.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -136,6 +142,92 @@ __global__ __launch_bounds__(256, BPC) void k(float* out, const float* __restric
     out[blockIdx.x * 256 + tid] = s + a0.x + (float)b0.x;
 }
 
+
+// MODE 6: pre-split operands, LDS-DMA staging.  KS = k-steps (of 16) per barrier.
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int BPC, int KS>
+__global__ __launch_bounds__(256, BPC) void kglds(float* out, const unsigned* __restrict__ ga3, const unsigned* __restrict__ gb3, int iters)
+{
+    constexpr int OPD = 3 * 128 * 8;                                // dwords of one operand image of one k-step: [term 3][row 128][8]
+    constexpr int BUF = KS * 2 * OPD;                               // [k-step][A | B]
+    __shared__ __attribute__((aligned(16))) unsigned lds[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < 2 * BUF; i += 256) lds[i] = 0x3f803f80u + (i & 7);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int g = lane >> 5, il = lane & 31, wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+    // this wave's three 1-KiB DMA pieces per operand and k-step: piece c = wid * 3 + s -> term c / 4, rows 32 (c % 4) .. + 31;
+    // lane l brings row + (l >> 1), 16-byte half (l & 1) ^ ((row >> 3) & 1)
+    unsigned srcoff[3], dstoff[3];
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int c = wid * 3 + s, term = c >> 2, row = (c & 3) * 32 + (lane >> 1);
+        const int half = (lane & 1) ^ ((row >> 3) & 1);
+        srcoff[s] = (unsigned)row * (64 * 24) + term * 8 + half * 4;          // dwords; [row][k-step 64][24]
+        dstoff[s] = (term * 128 + (c & 3) * 32) * 8;                           // dwords, wave-uniform (+ lane * 4 by the hardware)
+    }
+    const unsigned* pa = ga3 + (size_t)(blockIdx.x & 63) * 128 * 64 * 24;
+    const unsigned* pb = gb3;
+    auto dma = [&](int it, unsigned* buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kk = ((it * KS + ks) & 63) * 24;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                __builtin_amdgcn_global_load_lds((gptr_t)(pa + srcoff[s] + kk), (lptr_t)(buf + ks * 2 * OPD + dstoff[s]), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)(pb + srcoff[s] + kk), (lptr_t)(buf + ks * 2 * OPD + OPD + dstoff[s]), 16, 0, 0);
+            }
+        }
+    };
+    // fragment addresses: row's 16-byte half g sits in slot g ^ ((row >> 3) & 1)
+    int fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm0 + i * 32 + il, rb = wn0 + i * 32 + il;
+        fa[i] = ra * 8 + ((g ^ ((ra >> 3) & 1)) << 2);
+        fb[i] = rb * 8 + ((g ^ ((rb >> 3) & 1)) << 2);
+    }
+    dma(0, lds);
+    __syncthreads();
+    int cur = 0;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        const unsigned* cb = lds + cur * BUF;
+        dma(it + 1, lds + (cur ^ 1) * BUF);                          // next k-step(s): in flight under this step's MFMAs
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned* As = cb + ks * 2 * OPD;
+            const unsigned* Bs = As + OPD;
+            v4u af[2][3], bf[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    af[i][t] = *reinterpret_cast<const v4u*>(As + t * 128 * 8 + fa[i]);
+                    bf[i][t] = *reinterpret_cast<const v4u*>(Bs + t * 128 * 8 + fb[i]);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = mm(af[i][2], bf[j][0], acc[i][j]);
+                    acc[i][j] = mm(af[i][1], bf[j][1], acc[i][j]);
+                    acc[i][j] = mm(af[i][0], bf[j][2], acc[i][j]);
+                    acc[i][j] = mm(af[i][1], bf[j][0], acc[i][j]);
+                    acc[i][j] = mm(af[i][0], bf[j][1], acc[i][j]);
+                    acc[i][j] = mm(af[i][0], bf[j][0], acc[i][j]);
+                }
+        }
+        __syncthreads();                                             // (vmcnt(0) + barrier: the DMAs have landed, everyone is done reading `cur`)
+        cur ^= 1;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
 // the f32 MFMA loop (as tools/micro/mfma_peak.hip MODE 1, 2 x 2 tiles per wave: 4 A/B b128 reads per 16 MFMAs of 32x32x2)
 template <int BPC>
 __global__ __launch_bounds__(256, BPC) void kf32(float* out, int iters)
@@ -174,7 +266,7 @@ __global__ __launch_bounds__(256, BPC) void kf32(float* out, int iters)
     out[blockIdx.x * 256 + tid] = s;
 }
 
-static float* g_out; static float* g_a; static unsigned* g_b;
+static float* g_out; static float* g_a; static unsigned* g_b; static unsigned* g_a3; static unsigned* g_b3;
 
 template <int MODE, int BPC> double run(const char* name)
 {
@@ -191,6 +283,24 @@ template <int MODE, int BPC> double run(const char* name)
     }
     const double eq = (double)grid * 4 * iters * 4 * 2.0 * 32 * 32 * 16;      // fp32-equivalent flops
     const double tf = eq / best / 1e9;
+    printf("%-66s blocks/CU=%d  %8.3f ms  %7.1f TF fp32-equivalent  (%6.1f TF bf16 MFMA issued)\n", name, BPC, best, tf, tf * 6);
+    return tf;
+}
+
+template <int BPC, int KS> double runglds(const char* name)
+{
+    const int iters = 4000 / KS, grid = 256 * BPC;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kglds<BPC, KS><<<grid, 256>>>(g_out, g_a3, g_b3, 50);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        kglds<BPC, KS><<<grid, 256>>>(g_out, g_a3, g_b3, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double tf = (double)grid * 4 * iters * KS * 4 * 2.0 * 32 * 32 * 16 / best / 1e9;
     printf("%-66s blocks/CU=%d  %8.3f ms  %7.1f TF fp32-equivalent  (%6.1f TF bf16 MFMA issued)\n", name, BPC, best, tf, tf * 6);
     return tf;
 }
@@ -228,6 +338,13 @@ int main()
     const double s4 = run<4, 2>("bf16x3 pipelined: split interleaved with the MFMAs, loads 2 k-steps ahead");
     run<5, 1>("bf16x3 pipelined + sched_group_barrier (1 MFMA : 2 VALU)");
     run<5, 2>("bf16x3 pipelined + sched_group_barrier (1 MFMA : 2 VALU)");
+    hipMalloc(&g_a3, (size_t)64 * 128 * 64 * 24 * 4); hipMemset(g_a3, 0x3f, (size_t)64 * 128 * 64 * 24 * 4);      // 64 row blocks, pre-split
+    hipMalloc(&g_b3, (size_t)128 * 64 * 24 * 4); hipMemset(g_b3, 0x3f, (size_t)128 * 64 * 24 * 4);
+    runglds<1, 1>("bf16x3 stage C: both operands pre-split, LDS-DMA (K = 16 / barrier)");
+    const double c1 = runglds<2, 1>("bf16x3 stage C: both operands pre-split, LDS-DMA (K = 16 / barrier)");
+    const double c2 = runglds<1, 2>("bf16x3 stage C: both operands pre-split, LDS-DMA (K = 32 / barrier)");
+    printf("stage C go / no-go (>= 330 TF fp32-equivalent in the loop): %.1f (K16, 2 blocks/CU), %.1f (K32, 1 block/CU) -> %s\n", c1, c2,
+           (c1 >= 330.0 || c2 >= 330.0) ? "GO" : "NO-GO");
     runf32<1>();
     const double f = runf32<2>();
     printf("ratio: staged bf16x3 loop / f32 MFMA loop = %.2f (LDS-staged), %.2f (with global loads), %.2f (pipelined)   [kill criterion: < 1.3]\n", s2 / f, s3 / f, s4 / f);
