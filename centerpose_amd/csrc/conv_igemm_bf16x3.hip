@@ -7,6 +7,11 @@
 // bf16 x bf16 product is exact in fp32; the three dropped products (x2y3, x3y2, x3y3) are <= 2^-24 + 2^-24 + 2^-32 relative to
 // |xy| -- the size of ONE fp32 rounding of the product, which the f32 MFMA / an fmaf chain commits on every term anyway.  Measured
 // error against an fp64 convolution: tools/bf16x3_ab.py (profiles/r5_bf16x3_ab_*.txt).
+// DOMAIN: FINITE operands with |x| < 2^127.  bf16 has fp32's exponent range but rounds to nearest: the top binade's upper
+// half rounds to +-inf, and for x = +-inf (or such an x) the residual x - bf16(x) is inf - inf = NaN, so the split kernel returns NaN
+// where the f32 kernel propagates +-inf or a finite value; below 2^-110 the lower terms fall into bf16's subnormal range and the
+// result carries fewer than 24 significand bits (absolute error < 1e-40).  Post-BN activations and weights of a network are ~2^-20 ..
+// 2^20; tests/test_conv_hip.py::test_conv_split_bf16_magnitude_range pins 1e+-30.  Nothing selects this kernel by default.
 // Rate: 6 bf16 MFMAs (32 cycles each, K = 16) replace 8 f32 MFMAs (64 cycles each, K = 2): 192 vs 512 matrix-pipe cycles per
 // 32 x 32 x 16 tile step = 2.67x, ceiling 2516 / 6 = 419 TFLOP/s fp32-equivalent; and the split's VALU work runs BESIDE the
 // bf16 matrix pipe (the f32 MFMA shares the fp32 FMA lanes with the VALU: DESIGN 7.2).

@@ -103,6 +103,30 @@ def test_conv_split_bf16_matches_f32_kernel_tolerance(cin, cout, k, s, p, hw, bn
     assert e16 <= 2.0 * e32 + 1e-7
 
 
+@pytest.mark.parametrize("xs,ws", [(1e30, 1e-30), (1e-30, 1e30), (3e18, 3e18), (1e-19, 1e-19)])
+def test_conv_split_bf16_magnitude_range(xs, ws):
+    """the split-bf16 kernel's DOMAIN is finite operands below 2^127 (conv_igemm_bf16x3.hip header): across 60 binades of
+    operand magnitude -- products up to 1e37, down to 1e-38 -- it stays at the f32 kernel's relative error against an fp64 reference.
+    (Non-finite operands are outside the domain: inf - bf16(inf) is NaN in the residual where the f32 kernel propagates inf.)"""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(11)
+    B, C, Co, H, W = 2, 64, 64, 12, 12
+    x = torch.randn(B, C, H, W, generator=g) * xs
+    w = torch.randn(Co, C, 1, 1, generator=g) / 8 * ws
+    ref = F.conv2d(x.double(), w.double())
+    sc, sh = ops.fold_bn(Co, None, torch.zeros(Co).cuda())
+    wp = ops.pack_conv_weight(w.cuda())
+    err = {}
+    for mode in ("f32", "bf16x3"):
+        out = torch.empty(B, H, W, Co, device="cuda")
+        ops.conv2d([_nhwc(x)], wp, sc, sh, out, kh=1, kw=1, cout=Co, **({"tile": 64064} if mode == "f32" else {"split_bf16": True}))
+        got = out.permute(0, 3, 1, 2).cpu().double()
+        assert torch.isfinite(got).all()
+        err[mode] = ((got - ref).abs().max() / ref.abs().max()).item()
+    print("scale %g x %g: relative error vs fp64  f32 MFMA %.2e  split-bf16 %.2e" % (xs, ws, err["f32"], err["bf16x3"]))
+    assert err["bf16x3"] <= 2.0 * err["f32"] + 1e-7
+
+
 def test_conv_split_bf16_concat_deconv_splitk_nchw():
     """The other producers / epilogues of the generic kernel through the split-bf16 kernel: concatenated sources with channel views
     (DLA Root), the fused sub-pixel deconvolution (nsub = 4), split-K + fixed-order reduction, and the NCHW head output."""

@@ -73,4 +73,5 @@ def main():
               "bounds [%.1f, %.1f]" % (rep, pair, one, one_big, pair_big, pair / 1.2, one_big, pair_big))
 
 
-main()
+if __name__ == "__main__":
+    main()

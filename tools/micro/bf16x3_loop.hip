@@ -228,6 +228,170 @@ __global__ __launch_bounds__(256, BPC) void kglds(float* out, const unsigned* __
     out[blockIdx.x * 256 + tid] = s;
 }
 
+// MODE 6b: as kglds, but the DMA runs TWO k-steps ahead of the MFMAs through THREE LDS buffers, retired with a COUNTED s_waitcnt
+// vmcnt(6) (= this thread's 6 DMAs of the newest k-step may stay in flight) and a RAW s_barrier -- __syncthreads() would emit vmcnt(0)
+// and drain the newest DMA at every k-step (cdna_hip_programming.md "Pipelining across barriers").  NB = LDS buffers (3 or 4).
+// LAY: global layout of the pre-split operands -- 0: [row][k-step][term][16 bf16] (one 96-byte record per row and k-step: a DMA
+// instruction touches 32 records, 32 contiguous bytes each); 1: [k-step][term][row][16 bf16] (planes in the consumer's k-step order: a
+// DMA instruction reads 1 KiB contiguous)
+template <int BPC, int NB, int LAY>
+__global__ __launch_bounds__(256, BPC) void kglds3(float* out, const unsigned* __restrict__ ga3, const unsigned* __restrict__ gb3, int iters)
+{
+    constexpr int OPD = 3 * 128 * 8, BUF = 2 * OPD;
+    __shared__ __attribute__((aligned(16))) unsigned lds[NB * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < NB * BUF; i += 256) lds[i] = 0x3f803f80u + (i & 7);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int g = lane >> 5, il = lane & 31, wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+    unsigned srcA[3], srcB[3], dstoff[3];
+    constexpr unsigned ROWS_A = 64 * 128, ROWS_B = 128;              // rows of the whole A / B matrices
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        const int c = wid * 3 + s, term = c >> 2, row = (c & 3) * 32 + (lane >> 1);
+        const int half = (lane & 1) ^ ((row >> 3) & 1);
+        if (LAY == 0) srcA[s] = srcB[s] = (unsigned)row * (64 * 24) + term * 8 + half * 4;
+        else { srcA[s] = ((unsigned)term * ROWS_A + row) * 8 + half * 4; srcB[s] = ((unsigned)term * ROWS_B + row) * 8 + half * 4; }
+        dstoff[s] = (term * 128 + (c & 3) * 32) * 8;
+    }
+    const unsigned* pa = ga3 + (LAY == 0 ? (size_t)(blockIdx.x & 63) * 128 * 64 * 24 : (size_t)(blockIdx.x & 63) * 128 * 8);
+    const unsigned* pb = gb3;
+    auto dma = [&](int it, unsigned* buf) __attribute__((always_inline)) {
+        const unsigned ka = LAY == 0 ? (it & 63) * 24 : (unsigned)(it & 63) * (3 * ROWS_A * 8);
+        const unsigned kb = LAY == 0 ? (it & 63) * 24 : (unsigned)(it & 63) * (3 * ROWS_B * 8);
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(pa + srcA[s] + ka), (lptr_t)(buf + dstoff[s]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(pb + srcB[s] + kb), (lptr_t)(buf + OPD + dstoff[s]), 16, 0, 0);
+        }
+    };
+    int fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm0 + i * 32 + il, rb = wn0 + i * 32 + il;
+        fa[i] = ra * 8 + ((g ^ ((ra >> 3) & 1)) << 2);
+        fb[i] = rb * 8 + ((g ^ ((rb >> 3) & 1)) << 2);
+    }
+#pragma unroll
+    for (int d = 0; d < NB - 1; ++d) dma(d, lds + d * BUF);
+    if (NB == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = NB - 1;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        const unsigned* As = lds + cur * BUF;
+        const unsigned* Bs = As + OPD;
+        dma(it + NB - 1, lds + nxt * BUF);                           // NB - 1 k-steps ahead: its buffer was read in iteration it - 1
+        v4u af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                af[i][t] = *reinterpret_cast<const v4u*>(As + t * 128 * 8 + fa[i]);
+                bf[i][t] = *reinterpret_cast<const v4u*>(Bs + t * 128 * 8 + fb[i]);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = mm(af[i][2], bf[j][0], acc[i][j]);
+                acc[i][j] = mm(af[i][1], bf[j][1], acc[i][j]);
+                acc[i][j] = mm(af[i][0], bf[j][2], acc[i][j]);
+                acc[i][j] = mm(af[i][1], bf[j][0], acc[i][j]);
+                acc[i][j] = mm(af[i][0], bf[j][1], acc[i][j]);
+                acc[i][j] = mm(af[i][0], bf[j][0], acc[i][j]);
+            }
+        // the k-step read next must have landed (all but the newest NB - 2 k-steps' DMAs of this thread), fragment reads of `cur` retired
+        if (NB == 3) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur + 1 == NB ? 0 : cur + 1;
+        nxt = nxt + 1 == NB ? 0 : nxt + 1;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 256 + tid] = s;
+}
+
+// MODE 6c: the pipelined plane-layout loop on a 256 x 128 block tile (8 waves, each 64 x 64 as before): 36 KB of DMA per k-step for
+// twice the MFMAs of the 128 x 128 tile (-25 % operand bytes per flop).  3 LDS buffers = 108 KB: one block per CU, two waves per SIMD.
+__global__ __launch_bounds__(512, 1) void kglds256(float* out, const unsigned* __restrict__ ga3, const unsigned* __restrict__ gb3, int iters)
+{
+    constexpr int NB = 3, OPA = 3 * 256 * 8, OPB = 3 * 128 * 8, BUF = OPA + OPB;
+    __shared__ __attribute__((aligned(16))) unsigned lds[NB * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    for (int i = tid; i < NB * BUF; i += 512) lds[i] = 0x3f803f80u + (i & 7);
+    __syncthreads();
+    f32x16 acc[2][2];
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int g = lane >> 5, il = lane & 31, wm0 = (wid >> 1) * 64, wn0 = (wid & 1) * 64;
+    constexpr unsigned ROWS_A = 64 * 256, ROWS_B = 128;
+    // 36 one-KiB pieces per k-step: 24 of A (term c / 8, rows 32 (c % 8) ..), 12 of B; wave w brings pieces w, w + 8, ..., < 36
+    unsigned src[5], dst[5]; bool isB[5];
+    const int npc = wid < 4 ? 5 : 4;
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        const int c = wid + 8 * s;
+        const bool b = c >= 24;
+        const int cc = b ? c - 24 : c, rb = b ? 4 : 8;
+        const int term = cc / rb, row = (cc % rb) * 32 + (lane >> 1), half = (lane & 1) ^ ((row >> 3) & 1);
+        src[s] = ((unsigned)term * (b ? ROWS_B : ROWS_A) + row) * 8 + half * 4;
+        dst[s] = (b ? OPA : 0) + (term * (b ? 128 : 256) + (cc % rb) * 32) * 8;
+        isB[s] = b;
+    }
+    const unsigned* pa = ga3 + (size_t)(blockIdx.x & 63) * 256 * 8;
+    auto dma = [&](int it, unsigned* buf) __attribute__((always_inline)) {
+        const unsigned ka = (unsigned)(it & 31) * (3 * ROWS_A * 8), kb = (unsigned)(it & 31) * (3 * ROWS_B * 8);
+#pragma unroll
+        for (int s = 0; s < 5; ++s)
+            if (s < 4 || npc == 5)
+                __builtin_amdgcn_global_load_lds((gptr_t)(isB[s] ? gb3 + src[s] + kb : pa + src[s] + ka), (lptr_t)(buf + dst[s]), 16, 0, 0);
+    };
+    int fa[2], fb[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = wm0 + i * 32 + il, rb = wn0 + i * 32 + il;
+        fa[i] = ra * 8 + ((g ^ ((ra >> 3) & 1)) << 2);
+        fb[i] = rb * 8 + ((g ^ ((rb >> 3) & 1)) << 2);
+    }
+    dma(0, lds); dma(1, lds + BUF);
+    if (npc == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int cur = 0, nxt = 2;
+#pragma unroll 1
+    for (int it = 0; it < iters; ++it) {
+        const unsigned* As = lds + cur * BUF;
+        const unsigned* Bs = As + OPA;
+        dma(it + 2, lds + nxt * BUF);
+        v4u af[2][3], bf[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                af[i][t] = *reinterpret_cast<const v4u*>(As + t * 256 * 8 + fa[i]);
+                bf[i][t] = *reinterpret_cast<const v4u*>(Bs + t * 128 * 8 + fb[i]);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                acc[i][j] = mm(af[i][2], bf[j][0], acc[i][j]);
+                acc[i][j] = mm(af[i][1], bf[j][1], acc[i][j]);
+                acc[i][j] = mm(af[i][0], bf[j][2], acc[i][j]);
+                acc[i][j] = mm(af[i][1], bf[j][0], acc[i][j]);
+                acc[i][j] = mm(af[i][0], bf[j][1], acc[i][j]);
+                acc[i][j] = mm(af[i][0], bf[j][0], acc[i][j]);
+            }
+        if (npc == 5) asm volatile("s_waitcnt vmcnt(5) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        cur = cur == 2 ? 0 : cur + 1;
+        nxt = nxt == 2 ? 0 : nxt + 1;
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) for (int r = 0; r < 16; ++r) s += acc[i][j][r];
+    out[blockIdx.x * 512 + tid] = s;
+}
+
 // the f32 MFMA loop (as tools/micro/mfma_peak.hip MODE 1, 2 x 2 tiles per wave: 4 A/B b128 reads per 16 MFMAs of 32x32x2)
 template <int BPC>
 __global__ __launch_bounds__(256, BPC) void kf32(float* out, int iters)
@@ -304,6 +468,42 @@ template <int BPC, int KS> double runglds(const char* name)
     printf("%-66s blocks/CU=%d  %8.3f ms  %7.1f TF fp32-equivalent  (%6.1f TF bf16 MFMA issued)\n", name, BPC, best, tf, tf * 6);
     return tf;
 }
+
+template <int BPC, int NB, int LAY> double runglds3(const char* name)
+{
+    const int iters = 4000, grid = 256 * BPC;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kglds3<BPC, NB, LAY><<<grid, 256>>>(g_out, g_a3, g_b3, 50);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        kglds3<BPC, NB, LAY><<<grid, 256>>>(g_out, g_a3, g_b3, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double tf = (double)grid * 4 * iters * 4 * 2.0 * 32 * 32 * 16 / best / 1e9;
+    printf("%-66s blocks/CU=%d  %8.3f ms  %7.1f TF fp32-equivalent  (%6.1f TF bf16 MFMA issued)\n", name, BPC, best, tf, tf * 6);
+    return tf;
+}
+
+double runglds256(const char* name)
+{
+    const int iters = 4000, grid = 256;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    kglds256<<<grid, 512>>>(g_out, g_a3, g_b3, 50);
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        kglds256<<<grid, 512>>>(g_out, g_a3, g_b3, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        if (ms < best) best = ms;
+    }
+    const double tf = (double)grid * 8 * iters * 4 * 2.0 * 32 * 32 * 16 / best / 1e9;
+    printf("%-66s blocks/CU=%d  %8.3f ms  %7.1f TF fp32-equivalent  (%6.1f TF bf16 MFMA issued)\n", name, 1, best, tf, tf * 6);
+    return tf;
+}
 template <int BPC> double runf32()
 {
     const int iters = 4000, grid = 256 * BPC;
@@ -323,7 +523,7 @@ template <int BPC> double runf32()
 }
 int main()
 {
-    hipMalloc(&g_out, 256 * 4 * 256 * sizeof(float));
+    hipMalloc(&g_out, 256 * 4 * 512 * sizeof(float));
     hipMalloc(&g_a, 64 * 128 * 1024 * sizeof(float)); hipMemset(g_a, 0, 64 * 128 * 1024 * sizeof(float));
     hipMalloc(&g_b, 64 * 3072 * sizeof(unsigned)); hipMemset(g_b, 0, 64 * 3072 * sizeof(unsigned));
     run<0, 1>("bf16x3 register-fed (24 MFMA / k-step)");
@@ -343,8 +543,18 @@ int main()
     runglds<1, 1>("bf16x3 stage C: both operands pre-split, LDS-DMA (K = 16 / barrier)");
     const double c1 = runglds<2, 1>("bf16x3 stage C: both operands pre-split, LDS-DMA (K = 16 / barrier)");
     const double c2 = runglds<1, 2>("bf16x3 stage C: both operands pre-split, LDS-DMA (K = 32 / barrier)");
-    printf("stage C go / no-go (>= 330 TF fp32-equivalent in the loop): %.1f (K16, 2 blocks/CU), %.1f (K32, 1 block/CU) -> %s\n", c1, c2,
-           (c1 >= 330.0 || c2 >= 330.0) ? "GO" : "NO-GO");
+    runglds3<1, 3, 0>("bf16x3 stage C pipelined: DMA 2 k-steps ahead, 3 LDS buffers, vmcnt(6) + raw s_barrier");
+    const double c3 = runglds3<2, 3, 0>("bf16x3 stage C pipelined: DMA 2 k-steps ahead, 3 LDS buffers, vmcnt(6) + raw s_barrier");
+    const double c4 = runglds3<1, 4, 0>("bf16x3 stage C pipelined: DMA 3 k-steps ahead, 4 LDS buffers, vmcnt(12) + raw s_barrier");
+    runglds3<1, 3, 1>("bf16x3 stage C pipelined, PLANE layout [k-step][term][row][16] (1 KiB per DMA), 3 buffers");
+    const double c5 = runglds3<2, 3, 1>("bf16x3 stage C pipelined, PLANE layout [k-step][term][row][16] (1 KiB per DMA), 3 buffers");
+    const double c6 = runglds3<1, 4, 1>("bf16x3 stage C pipelined, PLANE layout, 4 buffers");
+    const double c7 = runglds256("bf16x3 stage C pipelined, PLANE layout, 256 x 128 block tile (8 waves), 3 buffers");
+    double best = c1 > c2 ? c1 : c2; best = c3 > best ? c3 : best; best = c4 > best ? c4 : best; best = c5 > best ? c5 : best; best = c6 > best ? c6 : best;
+    best = c7 > best ? c7 : best;
+    printf("plane layout: %.1f (3 buffers, 2 blocks/CU), %.1f (4 buffers, 1 block/CU), %.1f (256 x 128 tile, 8 waves)\n", c5, c6, c7);
+    printf("stage C go / no-go (>= 330 TF fp32-equivalent in the loop): %.1f (K16, 2 blocks/CU), %.1f (K32, 1 block/CU), %.1f (3 buffers, 2 blocks/CU), "
+           "%.1f (4 buffers, 1 block/CU) -> %s\n", c1, c2, c3, c4, best >= 330.0 ? "GO" : "NO-GO");
     runf32<1>();
     const double f = runf32<2>();
     printf("ratio: staged bf16x3 loop / f32 MFMA loop = %.2f (LDS-staged), %.2f (with global loads), %.2f (pipelined)   [kill criterion: < 1.3]\n", s2 / f, s3 / f, s4 / f);
