@@ -449,6 +449,56 @@ def test_detector_process_one_replay_equals_two_stage():
         flip.process(x)
 
 
+@pytest.mark.parametrize("arch", ["res_50", "hrnet"])
+def test_process_stream_equals_process_per_batch(arch, monkeypatch):
+    """MultiPoseDetector.process_stream on the device (the host logic alone is tests/test_host_logic.py::test_process_many_*): seven
+    batches of two shapes -- two full groups of the first shape, a group of MIXED shapes (FIX_RES = false: runs through `process`), a
+    full group of the second shape, an odd last batch -- every yielded (outputs, dets) torch.equal to `process(batch)`, in order;
+    `dets` are fresh tensors that survive later replays; the generator pulls at most `depth` batches ahead; the plan cache holds ONE
+    pipeline per shape and stays inside CP_ENGINE_CACHE; depth 3 as well; FLIP_TEST on: batch by batch through `process`."""
+    from centerpose_amd import config, detector, engine, synth
+    monkeypatch.setenv("CP_ENGINE_CACHE", "4")
+    cfg = config.get_cfg(arch, TEST__FLIP_TEST=False)
+    det = detector.MultiPoseDetector(cfg)
+    shapes = [(2, 128, 96)] * 4 + [(2, 128, 96), (2, 96, 128)] + [(2, 96, 128)] * 2 + [(2, 128, 96)]
+    batches = [synth.make_images(B, H, W, seed=60 + i).cuda() for i, (B, H, W) in enumerate(shapes)]
+    want = []
+    for x in batches:
+        outs, dets = det.process(x)
+        want.append([t.clone() for t in outs] + [dets.clone()])
+    torch.cuda.synchronize()
+    pulled = []
+
+    def source():
+        for i, x in enumerate(batches):
+            pulled.append(i)
+            yield x
+    got, kept = [], []
+    for i, (outs, dets) in enumerate(det.process_stream(source(), depth=2)):
+        assert len(pulled) <= 2 * (i // 2) + 2                                   # never more than one group ahead
+        got.append([t.clone() for t in outs] + [dets.clone()])
+        kept.append(dets)
+    torch.cuda.synchronize()
+    assert len(got) == len(batches)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert all(torch.equal(a, b) for a, b in zip(g, w)), "batch %d differs from process()" % i
+    assert all(torch.equal(k, w[6]) for k, w in zip(kept, want))                # fresh tensors: untouched by the later replays
+    pipes = {k: v for k, v in det.model._engines.items() if isinstance(v, engine.EnginePipeline)}
+    assert sorted(k[:3] for k in pipes) == [(2, 96, 128), (2, 128, 96)] and len(det.model._engines) <= 4
+    assert all(p.capture_mode == "2-stream" and p.engines[0] is det.model._engines.get(k[:4], p.engines[0]) for k, p in pipes.items())
+    got3 = [dets.clone() for _, dets in det.process_stream(batches[:4], depth=3)]                 # one joint replay of three + a single
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, w[6]) for a, w in zip(got3, want))
+    flip = detector.MultiPoseDetector(config.get_cfg(arch, TEST__FLIP_TEST=True))
+    pair = torch.cat([batches[0][:1], batches[0][:1].flip(3)], 0)
+    ref_o, ref_d = flip.process(pair)
+    ref_d = ref_d.clone()
+    res = list(flip.process_stream([pair, pair], depth=2))
+    torch.cuda.synchronize()
+    assert len(res) == 2 and all(torch.equal(d, ref_d) and d.shape[0] == 1 for _, d in res)
+    assert not any(isinstance(v, engine.EnginePipeline) for v in flip.model._engines.values())
+
+
 def test_full_size_batch_invariance_and_scaling_property(monkeypatch):
     """Size-independent properties at BASELINE's full 512x512 size (the oracle is too slow there): (1) an image's head
     maps do not depend on which batch it travels in - B=4 in one engine == the same images through a B=2 engine, bit for
