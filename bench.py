@@ -176,14 +176,22 @@ def cpu_baseline(arch):
         """P worker processes x T pinned threads, released together; aggregate = all images / the longest worker's time."""
         cmd = lambda i: [sys.executable, os.path.abspath(__file__), "--cpu-worker", "%s,%d,%d,%g,%d" % (a, B, T, secs, i * T)]
         procs = [subprocess.Popen(cmd(i), stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, cwd=ROOT) for i in range(P)]
+
+        def line(q, limit):
+            """one line of a worker's stdout, or an error after `limit` seconds: a stuck worker must not hang the bench line"""
+            import select
+            ready, _, _ = select.select([q.stdout], [], [], limit)
+            if not ready:
+                raise RuntimeError("cpu worker silent for %d s" % limit)
+            return q.stdout.readline()
         try:
             for q in procs:
-                if q.stdout.readline().strip() != "ready":
+                if line(q, 300).strip() != "ready":
                     raise RuntimeError("cpu worker did not come up")
             for q in procs:
                 q.stdin.write("go\n")
                 q.stdin.flush()
-            res = [json.loads(q.stdout.readline()) for q in procs]
+            res = [json.loads(line(q, 300 + 20 * secs)) for q in procs]
         finally:
             for q in procs:
                 try:
