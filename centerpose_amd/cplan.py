@@ -5,6 +5,8 @@ exactly what a C/C++ caller of libcenterpose_hip.so gets.  torch is used only to
     plan = CPlan("dla34_b16.cpplan")          # written by Engine.save_plan(...)
     heads = plan.forward(images)              # [hm, wh, hps, reg, hm_hp, hp_offset], NCHW views of the plan's buffers
     dets = plan.process(images, K=100)        # [B, K, 56]
+    pipe = CPipeline(plan, depth=2)           # two instances (the plan + a clone sharing its constants) in ONE hipGraph
+    dets_a, dets_b = pipe.process([images_a, images_b], K=100)
 """
 import ctypes
 
@@ -14,14 +16,16 @@ from . import _lib
 
 
 class CPlan:
-    def __init__(self, path_or_bytes, use_graph=True):
+    def __init__(self, path_or_bytes, use_graph=True, _clone_of=None):
         if not torch.cuda.is_available():
             raise _lib.CenterposeHipError("CPlan needs a HIP device; there is no CPU fallback")
         L = _lib.lib()
         L.cp_plan_input.restype = ctypes.c_void_p
         self._L = L
         self._h = ctypes.c_void_p()
-        if isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
+        if _clone_of is not None:
+            rc = L.cp_plan_clone(_clone_of._h, ctypes.byref(self._h))
+        elif isinstance(path_or_bytes, (bytes, bytearray, memoryview)):
             blob = bytes(path_or_bytes)
             rc = L.cp_plan_create(blob, ctypes.c_size_t(len(blob)), int(use_graph), ctypes.byref(self._h))
         else:
@@ -62,10 +66,57 @@ class CPlan:
         _lib.check(self._L.cp_plan_process(self._h, _lib.ptr(_lib.f32(images)), int(K), _lib.ptr(dets), _lib.stream()), "cp_plan_process")
         return dets
 
+    def clone(self):
+        """Another instance of this plan (`cp_plan_clone`): own activations and static buffers, the same constants."""
+        return CPlan(None, _clone_of=self)
+
     def close(self):
         if self._h:
             self._L.cp_plan_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CPipeline:
+    """Steps in flight through the C ABI alone (`cp_pipeline_*`): `depth` instances of one plan -- `plan` and depth - 1 clones --
+    captured into ONE hipGraph; `process([images_0, ...], K)` = one replay = one step of every instance, per instance bit-identical
+    to `CPlan.process`.  The plan must have been compiled with the decode inside its schedule (`Engine(..., decode_k=K)`)."""
+
+    def __init__(self, plan, depth=2):
+        self._L = plan._L
+        self.plans = [plan] + [plan.clone() for _ in range(depth - 1)]
+        self._h = ctypes.c_void_p()
+        arr = (ctypes.c_void_p * depth)(*[q._h.value for q in self.plans])
+        _lib.check(self._L.cp_pipeline_create(arr, depth, ctypes.byref(self._h)), "cp_pipeline_create")
+        self.depth = depth
+
+    def process(self, images, K=100):
+        if len(images) != self.depth:
+            raise ValueError("expected %d image batches" % self.depth)
+        p0 = self.plans[0]
+        for x in images:
+            if tuple(x.shape) != (p0.B, 3, p0.H, p0.W):
+                raise ValueError("plan was compiled for input %s, got %s" % ((p0.B, 3, p0.H, p0.W), tuple(x.shape)))
+        J = p0.output_shapes[4][1]
+        imgs = [_lib.f32(x) for x in images]
+        dets = [torch.empty((p0.B, K, 5 + 3 * J), dtype=torch.float32, device="cuda") for _ in range(self.depth)]
+        ia = (ctypes.c_void_p * self.depth)(*[x.data_ptr() for x in imgs])
+        da = (ctypes.c_void_p * self.depth)(*[d.data_ptr() for d in dets])
+        _lib.check(self._L.cp_pipeline_process(self._h, ia, int(K), da, _lib.stream()), "cp_pipeline_process")
+        return dets
+
+    def close(self):
+        if self._h:
+            self._L.cp_pipeline_destroy(self._h)
+            self._h = ctypes.c_void_p()
+        for q in self.plans[1:]:                      # the clones are this object's; plans[0] belongs to the caller
+            q.close()
+        self.plans = self.plans[:1]
 
     def __del__(self):
         try:

@@ -6,6 +6,7 @@
 // forward, sigmoid (fused), decode), without any Python.  The handle owns all device memory it allocates.
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 #include "common.h"
@@ -55,14 +56,23 @@ struct Op {
     std::vector<int> ints;
 };
 
-struct Out { float* p; int shape[4]; };
+struct Out { float* p; int shape[4]; int bufid; };
+
+// packed weights / folded scale-shift / Winograd U of one plan file: uploaded once, shared by the plan and its clones
+struct ConstPool {
+    std::vector<float*> p;
+    ~ConstPool() { for (float* q : p) if (q) (void)hipFree(q); }
+};
 
 }  // namespace
 
 struct cp_plan {
     int B = 0, H = 0, W = 0;
-    std::vector<float*> bufs, consts;
+    std::vector<float*> bufs;
+    std::vector<uint64_t> buf_numel;                 // floats per activation buffer (what cp_plan_clone allocates again)
+    std::shared_ptr<ConstPool> cpool;                // constants: owned jointly by a plan and its clones
     float* input = nullptr;
+    int input_buf = -1;
     std::vector<Out> outs;
     std::vector<Op> ops;
     bool use_graph = false, warmed = false;
@@ -183,9 +193,14 @@ int run_all(cp_plan* pl, hipStream_t s)
 // names; an op follows the last writer of each buffer it reads and the last writer / the readers of the buffer it writes
 // (RAW / WAW / WAR per activation buffer, derived here from the refs); edges that cross streams become event waits, which
 // the capture turns into graph edges.  Streams are FIFO, so per stream only the youngest awaited op matters.
-int run_two_streams(cp_plan* pl, hipStream_t main, hipStream_t side, std::vector<hipEvent_t>& ev)
+// A schedule entry = (op, capture stream, offset of its plan's buffer ids in one global numbering): the ops of SEVERAL plan
+// instances can be enqueued as one schedule (cp_pipeline_*: steps in flight) -- instances share no activation buffer, so no edge
+// ever connects them, and the constants they share are only read.
+struct SchedOp { const Op* op; int stream; int buf_base; };
+
+int run_schedule(const std::vector<SchedOp>& ops, size_t nb, hipStream_t main, hipStream_t side, std::vector<hipEvent_t>& ev)
 {
-    const size_t n = pl->ops.size(), nb = pl->bufs.size();
+    const size_t n = ops.size();
     std::vector<int> last_writer(nb, -1);
     std::vector<std::vector<int>> readers(nb);
     hipStream_t st[2] = {main, side};
@@ -194,13 +209,13 @@ int run_two_streams(cp_plan* pl, hipStream_t main, hipStream_t side, std::vector
     if (hipEventCreateWithFlags(&ev[n], hipEventDisableTiming) != hipSuccess || hipEventRecord(ev[n], main) != hipSuccess ||
         hipStreamWaitEvent(side, ev[n], 0) != hipSuccess) { cp_set_error("plan: fork of the side stream failed"); return 2; }
     for (size_t i = 0; i < n; ++i) {
-        const Op& o = pl->ops[i];
-        const int me = o.stream ? 1 : 0, other = me ^ 1;
+        const Op& o = *ops[i].op;
+        const int me = ops[i].stream ? 1 : 0, other = me ^ 1, base = ops[i].buf_base;
         int need = -1;                                   // youngest op of the other stream this one must follow
-        auto follow = [&](int j) { if (j >= 0 && (pl->ops[j].stream ? 1 : 0) == other && j > need) need = j; };
+        auto follow = [&](int j) { if (j >= 0 && (ops[j].stream ? 1 : 0) == other && j > need) need = j; };
         for (size_t k = 0; k < o.ptrs.size(); ++k) {
-            const int b = o.bufid[k];
-            if (b < 0) continue;
+            if (o.bufid[k] < 0) continue;
+            const int b = base + o.bufid[k];
             follow(last_writer[b]);
             if (k == o.out_index) for (int j : readers[b]) follow(j);
         }
@@ -215,14 +230,21 @@ int run_two_streams(cp_plan* pl, hipStream_t main, hipStream_t side, std::vector
         }
         tail[me] = (int)i;
         for (size_t k = 0; k < o.ptrs.size(); ++k) {
-            const int b = o.bufid[k];
-            if (b < 0) continue;
+            if (o.bufid[k] < 0) continue;
+            const int b = base + o.bufid[k];
             if (k == o.out_index) { last_writer[b] = (int)i; readers[b].clear(); }
             else readers[b].push_back((int)i);
         }
     }
     if (tail[1] >= 0 && hipStreamWaitEvent(main, ev[tail[1]], 0) != hipSuccess) { cp_set_error("plan: join of the side stream failed"); return 2; }
     return 0;
+}
+
+int run_two_streams(cp_plan* pl, hipStream_t main, hipStream_t side, std::vector<hipEvent_t>& ev)
+{
+    std::vector<SchedOp> ops;
+    for (const Op& o : pl->ops) ops.push_back(SchedOp{&o, (int)o.stream, 0});
+    return run_schedule(ops, pl->bufs.size(), main, side, ev);
 }
 
 void free_plan(cp_plan* pl)
@@ -233,7 +255,7 @@ void free_plan(cp_plan* pl)
     if (pl->cap_stream) (void)hipStreamDestroy(pl->cap_stream);
     if (pl->side_stream) (void)hipStreamDestroy(pl->side_stream);
     for (float* p : pl->bufs) if (p) (void)hipFree(p);
-    for (float* p : pl->consts) if (p) (void)hipFree(p);
+    pl->cpool.reset();                               // the constants go with their last owner
     if (pl->ws_scores) (void)hipFree(pl->ws_scores);
     if (pl->ws_inds) (void)hipFree(pl->ws_inds);
     delete pl;
@@ -284,7 +306,8 @@ extern "C" int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_
     cp_plan* pl = new cp_plan();
     pl->B = (int)B; pl->H = (int)H; pl->W = (int)W;
     pl->use_graph = use_graph != 0;
-    std::vector<uint64_t> buf_numel(nbuf);
+    std::vector<uint64_t>& buf_numel = pl->buf_numel;
+    buf_numel.resize(nbuf);
     for (uint32_t i = 0; i < nbuf; ++i) buf_numel[i] = r.u64();
     struct CI { uint64_t numel, off; };
     std::vector<CI> ci(nconst);
@@ -294,14 +317,16 @@ extern "C" int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_
         if (ci[i].off > bytes || ci[i].numel * 4 > bytes - ci[i].off) PLAN_FAIL("plan_create: constant %u lies outside the file", i);
     // ---- device memory: activations (zero-filled once) and constants
     pl->bufs.assign(nbuf, nullptr);
-    pl->consts.assign(nconst, nullptr);
+    pl->cpool = std::make_shared<ConstPool>();
+    std::vector<float*>& consts = pl->cpool->p;
+    consts.assign(nconst, nullptr);
     for (uint32_t i = 0; i < nbuf; ++i) {
         if (hipMalloc((void**)&pl->bufs[i], buf_numel[i] * 4 + 16) != hipSuccess) PLAN_FAIL("plan_create: hipMalloc of %llu floats failed", (unsigned long long)buf_numel[i]);
         (void)hipMemset(pl->bufs[i], 0, buf_numel[i] * 4);
     }
     for (uint32_t i = 0; i < nconst; ++i) {
-        if (hipMalloc((void**)&pl->consts[i], ci[i].numel * 4 + 16) != hipSuccess) PLAN_FAIL("plan_create: hipMalloc (constant) failed");
-        if (hipMemcpy(pl->consts[i], r.b + ci[i].off, ci[i].numel * 4, hipMemcpyHostToDevice) != hipSuccess)
+        if (hipMalloc((void**)&consts[i], ci[i].numel * 4 + 16) != hipSuccess) PLAN_FAIL("plan_create: hipMalloc (constant) failed");
+        if (hipMemcpy(consts[i], r.b + ci[i].off, ci[i].numel * 4, hipMemcpyHostToDevice) != hipSuccess)
             PLAN_FAIL("plan_create: upload of constant %u failed", i);
     }
     bool bad_ref = false;
@@ -312,15 +337,17 @@ extern "C" int cp_plan_create(const void* blob, size_t bytes, int use_graph, cp_
         last_buf = (f.kind == REF_BUF && f.id < nbuf) ? (int)f.id : -1;
         if (f.kind == REF_NULL) return nullptr;
         if (f.kind == REF_BUF && f.id < nbuf && f.off < buf_numel[f.id] && f.numel <= buf_numel[f.id] - f.off) return pl->bufs[f.id] + f.off;
-        if (f.kind == REF_CONST && f.id < nconst && f.numel <= ci[f.id].numel) return pl->consts[f.id];
+        if (f.kind == REF_CONST && f.id < nconst && f.numel <= ci[f.id].numel) return consts[f.id];
         bad_ref = true;
         return nullptr;
     };
     pl->input = resolve(r);
-    if (!pl->input) PLAN_FAIL("plan_create: plan has no input buffer");
+    pl->input_buf = last_buf;
+    if (!pl->input || pl->input_buf < 0) PLAN_FAIL("plan_create: plan has no input buffer");
     for (uint32_t i = 0; i < nout; ++i) {
         Out o;
         o.p = resolve(r);
+        o.bufid = last_buf;
         for (int k = 0; k < 4; ++k) o.shape[k] = (int)r.u32();
         pl->outs.push_back(o);
     }
@@ -456,6 +483,143 @@ extern "C" int cp_plan_process(cp_plan* pl, const float* images, int K, float* d
     }
     return cp_multi_pose_decode_f32(hm.p, pl->outs[1].p, pl->outs[2].p, pl->outs[3].p, pl->outs[4].p, pl->outs[5].p, B, cat, J, Hm, Wm, K,
                                     dets, pl->ws_scores, pl->ws_inds, stream);
+}
+
+// ---- steps in flight through the C ABI (round 6): what engine.EnginePipeline / MultiPoseDetector.process_stream do from Python ------
+// cp_plan_clone: a second INSTANCE of a loaded plan -- its own activation buffers, static input / outputs / detections, the SAME
+// constants (shared ownership: they are released with the last of the plan and its clones).  Nothing of the source's state is copied
+// (a clone captures its own graph on first use).
+extern "C" int cp_plan_clone(const cp_plan* src, cp_plan** out)
+{
+    CP_CHECK_ARG(src && out, "plan_clone: null pointer");
+    *out = nullptr;
+    cp_plan* pl = new cp_plan();
+    pl->B = src->B; pl->H = src->H; pl->W = src->W;
+    pl->use_graph = src->use_graph;
+    pl->buf_numel = src->buf_numel;
+    pl->cpool = src->cpool;
+    pl->bufs.assign(src->bufs.size(), nullptr);
+    for (size_t i = 0; i < src->bufs.size(); ++i) {
+        if (hipMalloc((void**)&pl->bufs[i], src->buf_numel[i] * 4 + 16) != hipSuccess) PLAN_FAIL("plan_clone: hipMalloc of %llu floats failed", (unsigned long long)src->buf_numel[i]);
+        (void)hipMemset(pl->bufs[i], 0, src->buf_numel[i] * 4);
+    }
+    auto remap = [&](float* p, int b) -> float* { return b < 0 ? p : pl->bufs[b] + (p - src->bufs[b]); };
+    pl->input_buf = src->input_buf;
+    pl->input = remap(src->input, src->input_buf);
+    for (const Out& o : src->outs) { Out c = o; c.p = remap(o.p, o.bufid); pl->outs.push_back(c); }
+    pl->ops = src->ops;
+    for (Op& o : pl->ops)
+        for (size_t k = 0; k < o.ptrs.size(); ++k) o.ptrs[k] = remap(o.ptrs[k], o.bufid[k]);
+    if (hipDeviceSynchronize() != hipSuccess) PLAN_FAIL("plan_clone: device error");
+    *out = pl;
+    return 0;
+}
+
+// cp_pipeline: `depth` instances of ONE plan (a loaded plan and its clones; compiled with the decode inside the schedule) whose
+// launch lists are enqueued TOGETHER on the two capture streams and captured into ONE hipGraph: one replay = `depth` independent
+// steps whose kernels fill each other's launch gaps and dependency-chain tails.  Placement: the ops are interleaved one by one
+// (op i of instance 0, op i of instance 1, ...), every instance keeps the two-stream placement its plan file carries, odd instances
+// with the two streams swapped -- so both capture streams carry the main chain of one instance and the side branches of the other.
+// (Python's engine.EnginePipeline re-runs its measured critical-path scheduler over both lists; round 5 measured a fixed
+// per-instance placement within 0-2 % of it.)  The pipeline does not own its plans.
+struct cp_pipeline {
+    std::vector<cp_plan*> plans;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap_stream = nullptr, side_stream = nullptr;
+};
+
+extern "C" int cp_pipeline_create(cp_plan* const* plans, int depth, cp_pipeline** out)
+{
+    CP_CHECK_ARG(plans && out && depth >= 1 && depth <= 8, "pipeline_create: 1..8 plan instances (got %d)", depth);
+    *out = nullptr;
+    for (int k = 0; k < depth; ++k) {
+        const cp_plan* q = plans[k];
+        CP_CHECK_ARG(q != nullptr, "pipeline_create: instance %d is NULL", k);
+        CP_CHECK_ARG(q->cpool == plans[0]->cpool && q->ops.size() == plans[0]->ops.size() && q->B == plans[0]->B && q->H == plans[0]->H && q->W == plans[0]->W,
+                     "pipeline_create: instance %d is not a clone of instance 0 (cp_plan_clone)", k);
+        for (int j = 0; j < k; ++j) CP_CHECK_ARG(plans[j] != q, "pipeline_create: instance %d given twice", k);
+        CP_CHECK_ARG(!q->ops.empty() && q->ops.back().fn == FN_ASSIGN && q->outs.size() == 6,
+                     "pipeline_create: the plan must be compiled with the decode inside its schedule (Engine(decode_k=K))");
+    }
+    cp_pipeline* pp = new cp_pipeline();
+    pp->plans.assign(plans, plans + depth);
+    *out = pp;
+    return 0;
+}
+
+extern "C" int cp_pipeline_destroy(cp_pipeline* pp)
+{
+    if (!pp) return 0;
+    (void)hipDeviceSynchronize();
+    if (pp->exec) (void)hipGraphExecDestroy(pp->exec);
+    if (pp->graph) (void)hipGraphDestroy(pp->graph);
+    if (pp->cap_stream) (void)hipStreamDestroy(pp->cap_stream);
+    if (pp->side_stream) (void)hipStreamDestroy(pp->side_stream);
+    delete pp;
+    return 0;
+}
+
+// One replay = one step of EVERY instance: images[k] (DEVICE float32 NCHW [B,3,H,W], or NULL / the instance's cp_plan_input() when the
+// caller wrote the static input itself) -> dets[k] (DEVICE float32 [B,K,5+3J]); K must be the decode_k the plan was compiled with.
+// Per instance bit-identical to cp_plan_process of that plan.  Enqueues on `stream`; no host synchronisation after the first call.
+extern "C" int cp_pipeline_process(cp_pipeline* pp, const float* const* images, int K, float* const* dets, void* stream)
+{
+    CP_CHECK_ARG(pp && dets, "pipeline_process: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t D = pp->plans.size();
+    for (size_t k = 0; k < D; ++k) {
+        cp_plan* pl = pp->plans[k];
+        CP_CHECK_ARG(dets[k] != nullptr, "pipeline_process: dets[%zu] is NULL", k);
+        CP_CHECK_ARG(pl->ops.back().ints[4] == K, "pipeline_process: the plan was compiled with decode_k = %d, asked for K = %d", pl->ops.back().ints[4], K);
+        if (images && images[k] && images[k] != pl->input) {
+            hipError_t e = hipMemcpyAsync(pl->input, images[k], (size_t)pl->B * 3 * pl->H * pl->W * 4, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) { cp_set_error("pipeline_process: input copy failed: %s", hipGetErrorString(e)); return 2; }
+        }
+    }
+    if (!pp->exec) {
+        auto fail = [&](int rc) {
+            if (pp->graph) { (void)hipGraphDestroy(pp->graph); pp->graph = nullptr; }
+            if (pp->side_stream) { (void)hipStreamDestroy(pp->side_stream); pp->side_stream = nullptr; }
+            if (pp->cap_stream) { (void)hipStreamDestroy(pp->cap_stream); pp->cap_stream = nullptr; }
+            pp->exec = nullptr;
+            return rc;
+        };
+        for (cp_plan* pl : pp->plans)                       // warm-up: kernel attributes, code objects -- and this call's results
+            if (int rc = run_all(pl, s)) return rc;
+        if (hipStreamSynchronize(s) != hipSuccess) { cp_set_error("pipeline_process: warm-up pass failed"); return 2; }
+        std::vector<SchedOp> ops;
+        size_t nb = 0;
+        std::vector<int> base(D);
+        for (size_t k = 0; k < D; ++k) { base[k] = (int)nb; nb += pp->plans[k]->bufs.size(); }
+        const size_t nops = pp->plans[0]->ops.size();
+        for (size_t i = 0; i < nops; ++i)
+            for (size_t k = 0; k < D; ++k) {
+                const Op& o = pp->plans[k]->ops[i];
+                ops.push_back(SchedOp{&o, (int)((o.stream ? 1 : 0) ^ (k & 1)), base[k]});
+            }
+        if (hipStreamCreateWithFlags(&pp->cap_stream, hipStreamNonBlocking) != hipSuccess) { pp->cap_stream = nullptr; cp_set_error("pipeline_process: stream create"); return fail(2); }
+        if (hipStreamCreateWithFlags(&pp->side_stream, hipStreamNonBlocking) != hipSuccess) { pp->side_stream = nullptr; cp_set_error("pipeline_process: stream create"); return fail(2); }
+        if (hipStreamBeginCapture(pp->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { cp_set_error("pipeline_process: begin capture"); return fail(2); }
+        std::vector<hipEvent_t> ev;
+        const int rc = run_schedule(ops, nb, pp->cap_stream, pp->side_stream, ev);
+        hipError_t e = hipStreamEndCapture(pp->cap_stream, &pp->graph);
+        for (hipEvent_t x : ev) if (x) (void)hipEventDestroy(x);
+        if (rc) return fail(rc);
+        if (e != hipSuccess || !pp->graph) { cp_set_error("pipeline_process: end capture: %s", hipGetErrorString(e)); return fail(2); }
+        e = hipGraphInstantiate(&pp->exec, pp->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) { cp_set_error("pipeline_process: graph instantiate: %s", hipGetErrorString(e)); return fail(2); }
+    } else {
+        hipError_t e = hipGraphLaunch(pp->exec, s);
+        if (e != hipSuccess) { cp_set_error("pipeline_process: graph launch: %s", hipGetErrorString(e)); return 2; }
+    }
+    for (size_t k = 0; k < D; ++k) {
+        const cp_plan* pl = pp->plans[k];
+        const int B = pl->outs[0].shape[0], J = pl->outs[4].shape[1];
+        hipError_t e = hipMemcpyAsync(dets[k], pl->ops.back().ptrs[6], (size_t)B * K * (5 + 3 * J) * 4, hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) { cp_set_error("pipeline_process: copy of the detections failed: %s", hipGetErrorString(e)); return 2; }
+    }
+    return 0;
 }
 
 extern "C" int cp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream)

@@ -257,6 +257,24 @@ int cp_plan_output(const cp_plan* plan, int i, float** dev_ptr, int shape[4]);
 int cp_plan_forward(cp_plan* plan, const float* images, void* stream);
 int cp_plan_process(cp_plan* plan, const float* images, int K, float* dets, void* stream);
 int cp_plan_destroy(cp_plan* plan);
+
+/* ---- steps in flight (round 6): the C-ABI form of MultiPoseDetector.process_stream / engine.EnginePipeline ----------------------
+ * Replaces nothing in the reference (it runs one image at a time, synchronously: lib/detectors/base_detector.py:79-140,
+ * multi_pose.py:29-60); it is how the timed arrangement of bench.py is reached without Python.
+ * cp_plan_clone: another INSTANCE of a loaded plan -- own activation buffers / static input / outputs / detections, the same
+ *   constants (shared; freed with the last of the plan and its clones).  Destroy clones with cp_plan_destroy like any plan.
+ * cp_pipeline_create: `depth` (1..8) instances of ONE plan (the plan and its clones, compiled with the decode inside the schedule:
+ *   Engine(decode_k = K)) -> a handle that captures all their launch lists into ONE hipGraph on first use (both capture streams carry
+ *   launches of several instances).  Does not take ownership of the plans; destroy the pipeline before its plans.
+ * cp_pipeline_process: one replay = one step of EVERY instance.  images[k]: DEVICE float32 NCHW [B,3,H,W] (NULL = the caller filled
+ *   cp_plan_input(plans[k]) itself); dets[k]: DEVICE float32 [B,K,5+3J] out; per instance bit-identical to cp_plan_process.
+ *   Enqueues on `stream`; the results of all instances are complete when the stream reaches the end of this call's work
+ *   (throughput up, a batch's latency ~ depth x: INTEGRATION.md 3c). */
+typedef struct cp_pipeline cp_pipeline;
+int cp_plan_clone(const cp_plan* plan, cp_plan** out);
+int cp_pipeline_create(cp_plan* const* plans, int depth, cp_pipeline** out);
+int cp_pipeline_process(cp_pipeline* pipe, const float* const* images, int K, float* const* dets, void* stream);
+int cp_pipeline_destroy(cp_pipeline* pipe);
 /* stream-ordered device-to-device copy (for callers that keep a plan's outputs beyond the next forward) */
 int cp_memcpy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 

@@ -4,6 +4,7 @@
 Tolerances (north_star: "heatmap/offset floats within 1e-3", indices bit-exact on identical decode
 inputs): post-sigmoid hm / hm_hp, reg, hp_offset: |err| <= 1e-3 absolute; wh / hps (tens of pixels):
 |err| <= 1e-3 * max|ref|.  fp32-in / fp32-accumulate MFMA actually lands ~1e-5."""
+import ctypes
 import os
 
 import numpy as np
@@ -257,6 +258,50 @@ def test_c_plan_handle_runs_network_without_engine(arch, B, hw, tmp_path):
         for i in range(6):
             assert np.array_equal(got["h%d" % i], ref[i].cpu().numpy()), (g, i)
         assert np.array_equal(got["dets"], ref_dets.cpu().numpy())
+
+
+@pytest.mark.parametrize("arch,depth", [("dla_34", 2), ("hrnet", 3)])
+def test_c_pipeline_steps_in_flight_equal_single_plan(arch, depth, tmp_path):
+    """Steps in flight through the C ABI alone (round 6: cp_plan_clone / cp_pipeline_create / cp_pipeline_process / cp_pipeline_destroy,
+    include/centerpose_hip.h) -- the C form of MultiPoseDetector.process_stream: `depth` instances of one plan file (clones share the
+    constants) captured into ONE hipGraph by the C runtime.  Per instance the detections equal cp_plan_process of the same batch bit for
+    bit, over several replays with changing inputs; the clones outlive the plan they were cloned from (shared constants)."""
+    from centerpose_amd import cplan, engine, synth
+    B, H, W = 2, 128, 96
+    eng = engine.Engine(arch, synth.make_state_dict(arch, seed=9), B, H, W, use_graph=True, decode_k=100)
+    path = str(tmp_path / "p.cpplan")
+    eng.save_plan(path)
+    imgs = [synth.make_images(B, H, W, seed=80 + i).cuda() for i in range(2 * depth)]
+    want = [eng.process(x)[1].clone() for x in imgs]                      # the Python engine ...
+    plan = cplan.CPlan(path)
+    single = [plan.process(x, 100).clone() for x in imgs]                 # ... and the single C plan agree
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(single, want))
+    pipe = cplan.CPipeline(plan, depth=depth)
+    got = []
+    for r in range(2):                                                    # first call: warm-up + capture; second: graph replay
+        got += pipe.process(imgs[r * depth:(r + 1) * depth], 100)
+    again = pipe.process(imgs[:depth], 100)                               # replay with the first inputs again
+    torch.cuda.synchronize()
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g, w), "instance %d of replay %d differs from the single plan" % (i % depth, i // depth)
+    assert all(torch.equal(a, w) for a, w in zip(again, want[:depth]))
+    with pytest.raises(Exception):
+        pipe.process(imgs[:depth], 50)                                    # not the K the plan was compiled with
+    other = cplan.CPlan(path)                                             # an independently loaded plan is NOT a clone: own constants
+    h = ctypes.c_void_p()
+    arr = (ctypes.c_void_p * 2)(plan._h.value, other._h.value)
+    assert plan._L.cp_pipeline_create(arr, 2, ctypes.byref(h)) != 0 and b"not a clone" in plan._L.cp_last_error()
+    other.close()
+    # the clones keep the shared constants alive when the source plan goes first
+    clone = plan.clone()
+    first = clone.process(imgs[0], 100).clone()
+    pipe.close()
+    plan.close()
+    second = clone.process(imgs[0], 100)
+    torch.cuda.synchronize()
+    assert torch.equal(first, want[0]) and torch.equal(second, want[0])
+    clone.close()
 
 
 def test_pybind_ext_plan_and_decode(tmp_path, golden_dir):
