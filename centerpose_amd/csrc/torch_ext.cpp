@@ -165,10 +165,10 @@ int64_t plan_create(const std::string& path, bool use_graph)
 // the same flat plan blob a file would hold, handed to cp_plan_create without touching the disk.  state_dict: the reference's
 // checkpoint["state_dict"] (lib/models/model.py:67-120; a leading "module." is stripped); head_conv: cfg.MODEL.HEAD_CONV or None.
 int64_t plan_create_from_state_dict(const std::string& arch, const py::dict& state_dict, int B, int H, int W, const py::object& head_conv,
-                                    bool use_graph)
+                                    bool use_graph, const py::object& decode_k)
 {
     py::object compile = py::module_::import("centerpose_amd.plan").attr("compile_state_dict");
-    const std::string blob = py::bytes(compile(arch, state_dict, B, H, W, head_conv));
+    const std::string blob = py::bytes(compile(arch, state_dict, B, H, W, head_conv, decode_k));
     cp_plan* p = nullptr;
     CP_CALL(cp_plan_create(blob.data(), blob.size(), use_graph ? 1 : 0, &p), "cp_plan_create");
     return reinterpret_cast<int64_t>(p);
@@ -215,6 +215,59 @@ at::Tensor plan_process(int64_t handle, const at::Tensor& images, int K)
 
 void plan_destroy(int64_t handle) { cp_plan_destroy(reinterpret_cast<cp_plan*>(handle)); }
 
+// Steps in flight (round 6; the C-ABI form of MultiPoseDetector.process_stream): `depth` instances of the plan behind `handle` -- the
+// plan itself and depth - 1 clones that share its constants -- captured into ONE hipGraph.  The pipeline handle owns the clones.
+struct PipelineBox {
+    cp_pipeline* pipe = nullptr;
+    std::vector<cp_plan*> plans;            // plans[0] belongs to the caller
+};
+
+int64_t pipeline_create(int64_t handle, int depth)
+{
+    TORCH_CHECK(handle != 0 && depth >= 1 && depth <= 8, "pipeline_create: a plan handle and 1 <= depth <= 8");
+    auto* box = new PipelineBox();
+    box->plans.push_back(reinterpret_cast<cp_plan*>(handle));
+    auto release = [&]() {
+        for (size_t k = 1; k < box->plans.size(); ++k) cp_plan_destroy(box->plans[k]);
+        delete box;
+    };
+    for (int k = 1; k < depth; ++k) {
+        cp_plan* c = nullptr;
+        if (cp_plan_clone(box->plans[0], &c)) { release(); TORCH_CHECK(false, "cp_plan_clone failed: ", cp_last_error()); }
+        box->plans.push_back(c);
+    }
+    if (cp_pipeline_create(box->plans.data(), depth, &box->pipe)) { release(); TORCH_CHECK(false, "cp_pipeline_create failed: ", cp_last_error()); }
+    return reinterpret_cast<int64_t>(box);
+}
+
+std::vector<at::Tensor> pipeline_process(int64_t handle, const std::vector<at::Tensor>& images, int K)
+{
+    auto* box = reinterpret_cast<PipelineBox*>(handle);
+    TORCH_CHECK(box && images.size() == box->plans.size(), "pipeline_process: expected ", box ? box->plans.size() : 0, " image batches");
+    std::vector<const float*> in;
+    std::vector<float*> out;
+    std::vector<at::Tensor> dets;
+    float* ptr; int shp[4];
+    CP_CALL(cp_plan_output(box->plans[0], 4, &ptr, shp), "cp_plan_output");       // hm_hp: J planes
+    for (const at::Tensor& x : images) {
+        check_plan_input(box->plans[0], x);
+        in.push_back(x.data_ptr<float>());
+        dets.push_back(at::empty({x.size(0), K, 5 + 3 * shp[1]}, x.options()));
+        out.push_back(dets.back().data_ptr<float>());
+    }
+    CP_CALL(cp_pipeline_process(box->pipe, in.data(), K, out.data(), cur_stream(images[0])), "cp_pipeline_process");
+    return dets;
+}
+
+void pipeline_destroy(int64_t handle)
+{
+    auto* box = reinterpret_cast<PipelineBox*>(handle);
+    if (!box) return;
+    cp_pipeline_destroy(box->pipe);
+    for (size_t k = 1; k < box->plans.size(); ++k) cp_plan_destroy(box->plans[k]);
+    delete box;
+}
+
 }  // namespace
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -227,8 +280,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("hm_hp") = py::none(), py::arg("hp_offset") = py::none(), py::arg("K") = 100, py::arg("return_indices") = false);
     m.def("plan_create", &plan_create, py::arg("path"), py::arg("use_graph") = true);
     m.def("plan_create_from_state_dict", &plan_create_from_state_dict, py::arg("arch"), py::arg("state_dict"), py::arg("B"), py::arg("H"),
-          py::arg("W"), py::arg("head_conv") = py::none(), py::arg("use_graph") = true);
+          py::arg("W"), py::arg("head_conv") = py::none(), py::arg("use_graph") = true, py::arg("decode_k") = py::none());
     m.def("plan_forward", &plan_forward);
     m.def("plan_process", &plan_process, py::arg("handle"), py::arg("images"), py::arg("K") = 100);
     m.def("plan_destroy", &plan_destroy);
+    m.def("pipeline_create", &pipeline_create, py::arg("plan_handle"), py::arg("depth") = 2);
+    m.def("pipeline_process", &pipeline_process, py::arg("handle"), py::arg("images"), py::arg("K") = 100);
+    m.def("pipeline_destroy", &pipeline_destroy);
 }

@@ -185,14 +185,16 @@ def save_plan(engine, path, deterministic=False):
     return len(blob)
 
 
-def compile_state_dict(arch, state_dict, B, H, W, head_conv=None):
+def compile_state_dict(arch, state_dict, B, H, W, head_conv=None, decode_k=None):
     """checkpoint tensors -> plan bytes (plan_create(arch, state_dict tensors, B, H, W)): what
     `_ext.plan_create_from_state_dict` hands to cp_plan_create.  state_dict: the reference's checkpoint["state_dict"]
     (lib/models/model.py:67-120; "module." prefixes are stripped); hm / hm_hp sigmoided as MultiPoseDetector.process does;
-    deterministic model schedule (no timing passes)."""
+    deterministic model schedule (no timing passes).  decode_k: multi_pose_decode(K = decode_k) as the last two launches of the
+    schedule (forward + decode = one replay; required by `cp_pipeline_*` / `_ext.pipeline_create`)."""
     from . import engine as _engine
     sd = {k: (v if torch.is_tensor(v) else torch.as_tensor(v)) for k, v in dict(state_dict).items()}
-    eng = _engine.Engine(arch, sd, int(B), int(H), int(W), head_conv=head_conv, sigmoid_heads=("hm", "hm_hp"), use_graph=False)
+    eng = _engine.Engine(arch, sd, int(B), int(H), int(W), head_conv=head_conv, sigmoid_heads=("hm", "hm_hp"), use_graph=False,
+                         decode_k=int(decode_k) if decode_k else None)
     return plan_blob(eng, deterministic=True)
 
 

@@ -335,6 +335,33 @@ def test_pybind_ext_plan_and_decode(tmp_path, golden_dir):
     assert np.array_equal(inds.cpu().numpy(), g["inds"]) and np.array_equal(hm_inds.cpu().numpy(), g["hm_inds"])
 
 
+def test_pybind_ext_pipeline_from_state_dict():
+    """`_ext.plan_create_from_state_dict(..., decode_k=K)` + `_ext.pipeline_create / pipeline_process / pipeline_destroy` (round 6): the
+    reference-shaped pybind module reaches the steps-in-flight arrangement from a checkpoint in three calls, no plan file; per batch the
+    detections equal `_ext.plan_process` of the same handle and the Python detector's `process`."""
+    from centerpose_amd import _ext, config, detector, synth
+    cfg = config.get_cfg("res_50", TEST__FLIP_TEST=False)
+    det = detector.MultiPoseDetector(cfg)
+    B, H, W = 2, 128, 128
+    imgs = [synth.make_images(B, H, W, seed=90 + i).cuda() for i in range(4)]
+    want = [det.process(x)[1].clone() for x in imgs]
+    h = _ext.plan_create_from_state_dict("res_50", det.model.state_dict(), B, H, W, head_conv=cfg.MODEL.HEAD_CONV, use_graph=True, decode_k=100)
+    single = [_ext.plan_process(h, x, 100) for x in imgs]
+    pipe = _ext.pipeline_create(h, 2)
+    got = _ext.pipeline_process(pipe, imgs[0:2], 100) + _ext.pipeline_process(pipe, imgs[2:4], 100) + _ext.pipeline_process(pipe, imgs[0:2], 100)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(single, want))
+    assert all(torch.equal(a, b) for a, b in zip(got, want + want[:2]))
+    with pytest.raises(RuntimeError):
+        _ext.pipeline_process(pipe, imgs[0:1], 100)                      # one batch for a depth-2 pipeline
+    _ext.pipeline_destroy(pipe)
+    h2 = _ext.plan_create_from_state_dict("res_50", det.model.state_dict(), B, H, W, head_conv=cfg.MODEL.HEAD_CONV)     # no decode inside
+    with pytest.raises(RuntimeError, match="decode"):
+        _ext.pipeline_create(h2, 2)
+    _ext.plan_destroy(h2)
+    _ext.plan_destroy(h)
+
+
 @pytest.mark.parametrize("arch,head_conv", [("dla_34", 256), ("res_50", 64)])
 def test_pybind_ext_plan_create_from_state_dict(arch, head_conv):
     """SURVEY 8b item 3 as written: plan_create(arch, state_dict tensors, B, H, W) -- `_ext.plan_create_from_state_dict` compiles the
