@@ -10,14 +10,21 @@ RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment.
 
 One "step" = one pass of the hot path over one batch of 16 synthetic images per GPU
 (BASELINE.json configs[2]; at N = 8 this is configs[3]: global batch 128 sharded 16/GPU with an RCCL
-all-gather of the decoded poses, issued on a side stream so it overlaps the next batch's backbone).  Prints ONE JSON line
+all-gather of the decoded poses, issued on a side stream so it overlaps the next batch's backbone).  The timed loop goes through the
+PRODUCT entry point -- `for outputs, dets in MultiPoseDetector.process_stream(batches, depth=D)` on the object
+`detector_factory['multi_pose'](cfg)` returns (the replacement of lib/detectors/multi_pose.py:29-60): D = --in-flight (default 2)
+consecutive batches captured into ONE hipGraph; D = 1 is `MultiPoseDetector.process` per batch and rides along as
+`config.one_step_in_flight`.  Per-step input copy and fresh `dets` are inside the timing.  Prints ONE JSON line
 on rank 0 with the contract's keys plus
 
 * `roofline`: the DOMINANT kernel of the step by time (kernel families timed live, in sequence, with HIP events on the
   launch stream): achieved = MFMA FLOPs the kernel executes per second (for a Winograd family 16/36 of the algorithmic
   direct-convolution count, which is reported next to it), peak = 157.3 TFLOP/s fp32 MFMA; every family's share is listed;
 * `cpu_baseline`: the oracle's torch-CPU restatement of the same path timed on this box's host cores (bounded sample),
-  dla_34 (the metric's workload) plus res_50 B=1 / B=8 split forward / decode (BASELINE.json configs[0]).
+  dla_34 (the metric's workload) plus res_50 B=1 / B=8 split forward / decode (BASELINE.json configs[0]), single- and multi-process
+  layouts, and the cgroup CPU quota that explains them;
+* `other_configs` (N = 1): res_50 B=8 (configs[1]), hrnet B=8 (per-GPU shape of configs[4]), the opt-in split-bf16 mode, and the
+  single-image `detector.run()` latency of the shipped dla_34 configuration -- all after the timed region.
 """
 import argparse
 import json
