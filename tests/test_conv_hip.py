@@ -680,6 +680,41 @@ def test_dcn_v2_forward_full_argument_space(C, Co, kh, kw, sh, sw, ph, pw, dh, d
         ext.dcn_v2_forward(*t, kh + 1, kw, sh, sw, ph, pw, dh, dw, dg)                # kernel size does not match the weight
 
 
+def test_dcn_v2_forward_random_argument_fuzz():
+    """Seeded fuzz over the argument space of `dcn_v2_forward` (DCNv2/src/cuda/dcn_v2_cuda.cu:43-57): 24 random combinations of channel
+    counts, kernel size (1..5 per axis), stride (1..3), pad (0..3), dilation (1..2) per axis and deformable groups, through the pybind
+    face against oracle/dcn_ref.c -- every output shape and every value (1e-4)."""
+    from centerpose_amd import _ext
+    from oracle import dcn as odcn
+    r = np.random.RandomState(2024)
+    done = 0
+    while done < 24:
+        dg = int(r.choice([1, 1, 2, 3]))
+        C = dg * int(r.choice([4, 8, 16, 24]))
+        Co = int(r.choice([3, 8, 17, 40]))
+        kh, kw = int(r.randint(1, 6)), int(r.randint(1, 6))
+        sh, sw = int(r.randint(1, 4)), int(r.randint(1, 4))
+        ph, pw = int(r.randint(0, 4)), int(r.randint(0, 4))
+        dh, dw = int(r.randint(1, 3)), int(r.randint(1, 3))
+        B, H, W = 2, int(r.randint(7, 15)), int(r.randint(7, 15))
+        Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+        Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+        if Ho < 1 or Wo < 1:
+            continue
+        kk = kh * kw
+        x = r.randn(B, C, H, W).astype(np.float32)
+        w = (r.randn(Co, C, kh, kw) / np.sqrt(C * kk)).astype(np.float32)
+        b = r.randn(Co).astype(np.float32)
+        off = (r.randn(B, 2 * dg * kk, Ho, Wo) * 1.5).astype(np.float32)
+        m = r.rand(B, dg * kk, Ho, Wo).astype(np.float32)
+        ref = odcn.dcn_v2_forward_c(x, w, b, off, m, kh, kw, sh, sw, ph, pw, dh, dw, dg)
+        out = _ext.dcn_v2_forward(*(torch.from_numpy(a).cuda() for a in (x, w, b, off, m)), kh, kw, sh, sw, ph, pw, dh, dw, dg)
+        assert tuple(out.shape) == ref.shape, (C, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg)
+        err = (out.cpu() - torch.from_numpy(ref)).abs().max().item()
+        assert err <= 1e-4 * max(1.0, float(np.abs(ref).max())), ((C, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg), err)
+        done += 1
+
+
 @pytest.mark.parametrize("face", ["python", "pybind"])
 def test_dcn_v2_forward_follows_every_kind_of_parameter_update(face):
     """The ext faces pack the weights with one device launch per call (round 5; rounds 3-4 cached the pack on (data_ptr, _version)).
