@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0
-MFMA_KERNELS = ("dcn_igemm_kernel", "conv3x3_wino", "head_wino24_kernel", "igemm_conv_kernel", "igemm_bf16x3_kernel", "conv3x3_patch_kernel", "conv3x3_c16_kernel", "stem7x7_kernel", "stem7x7_c16_kernel")
+MFMA_KERNELS = ("dcn_igemm_kernel", "conv3x3_wino", "head_wino24_kernel", "igemm_conv_kernel", "pw_conv_kernel", "igemm_bf16x3_kernel", "conv3x3_patch_kernel", "conv3x3_c16_kernel", "stem7x7_kernel", "stem7x7_c16_kernel")
 
 
 def parse_args():

@@ -9,6 +9,7 @@
 //   KeypointHead convs (+bias, +sigmoid)      lib/models/heads/keypoint.py:14-42, multi_pose.py:35-37
 // A-producers: NHWC im2col gather (any kh,kw,stride,pad) and a scalar gather for the 3-channel
 // NCHW network input (7x7 / 3x3 stems).
+#include <cstdlib>
 #include "igemm.h"
 
 // per-thread description of the output pixels whose A rows this thread stages
@@ -393,6 +394,16 @@ extern "C" int cp_conv2d_f32(const cp_conv_desc* d, const float* const* src, con
             return 0;
         }
         CP_CHECK_ARG(tile == 0, "conv2d: patch kernel requested for an ineligible shape");
+    }
+    if (!d->inNCHW && (tile == 0 || tile == 1)) {   // short-K 1x1 layers that are HBM-bound: everything requested up front (conv_pointwise.hip)
+        const char* sw = getenv("CP_POINTWISE");     // "0": the generic kernel for these too (A/B switch; read when a launch is recorded)
+        const int prc = (tile == 0 && sw && sw[0] == '0') ? -1 : cp_launch_conv_pointwise(a, s);
+        if (prc >= 0) {
+            if (prc) return prc;
+            CP_CHECK_LAUNCH("pw_conv_kernel");
+            return 0;
+        }
+        CP_CHECK_ARG(tile == 0, "conv2d: pointwise kernel requested for an ineligible shape");
     }
     if (tile == 0) {
         // heuristic: N tile from the padded channel count, M tile from how many blocks fill 256 CUs

@@ -80,6 +80,9 @@ int cp_launch_conv3x3_wino24(const ConvArgs& a, hipStream_t s);
 // conv3x3_wino.hip: [3x3 + bias + ReLU] + 1x1 (n2 <= 2 outputs, NCHW) of a head branch in one launch; -1 = shape not eligible
 int cp_launch_head3x3_1x1(const ConvArgs& a, const float* w2, const float* b2, float* out2, int n2, int ld2, int act2, hipStream_t s);
 
+// conv_pointwise.hip: 1x1 / stride 1 with K = 64 from one NHWC source, whole operand tiles + residual requested up front (bit-identical to the
+// generic kernel).  -1 = not eligible
+int cp_launch_conv_pointwise(const ConvArgs& a, hipStream_t s);
 // conv_igemm_bf16x3.hip: the generic implicit GEMM as an fp32-equivalent 3-term split on the bf16 matrix pipe (opt-in; a.w = pre-split weights)
 int cp_launch_conv_bf16x3(const ConvArgs& a, int tile, hipStream_t s);
 

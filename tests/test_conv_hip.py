@@ -103,6 +103,51 @@ def test_conv_split_bf16_matches_f32_kernel_tolerance(cin, cout, k, s, p, hw, bn
     assert e16 <= 2.0 * e32 + 1e-7
 
 
+@pytest.mark.parametrize("cin,cout,B,hw,res,act", [(64, 256, 3, (33, 17), True, 1), (64, 64, 2, (16, 16), False, 0), (64, 512, 2, (20, 13), True, 0),
+                                                   (64, 128, 1, (9, 130), False, 1), (64, 40, 2, (12, 12), True, 1)])
+def test_conv_pointwise_kernel_bit_identical_to_generic(cin, cout, B, hw, res, act):
+    """conv_pointwise.hip (round 6): the short-K 1x1 kernel that requests its whole A / weight / residual tiles up front (the HBM-bound
+    Bottleneck conv3 / downsample layers, msra_resnet.py:82-102) -- forced with tile code 1 -- against the generic implicit-GEMM kernel
+    (tile 64064) on the same inputs: BIT-IDENTICAL (same accumulation order, same epilogue expression), and both against torch;
+    ragged M (edge tiles), output channels that are not a multiple of the 64-wide tile, with / without residual and ReLU.  An
+    ineligible shape asked for by code raises instead of falling back."""
+    from centerpose_amd import _lib, ops
+    g = torch.Generator().manual_seed(cin + cout)
+    H, W = hw
+    x = torch.randn(B, cin, H, W, generator=g)
+    w = torch.randn(cout, cin, 1, 1, generator=g) / cin ** 0.5
+    bn = _rand_bn(g, cout)
+    r = torch.randn(B, cout, H, W, generator=g) if res else None
+    ref = _ref_bn(F.conv2d(x, w), bn)
+    if res:
+        ref = ref + r
+    if act:
+        ref = F.relu(ref)
+    wp = ops.pack_conv_weight(w.cuda())
+    sc, sh = ops.fold_bn(cout, tuple(t.cuda() for t in bn))
+    outs = {}
+    for tile in (1, 64064):
+        buf = torch.full((B, H, W, cout + 8), float("nan"), device="cuda")
+        out = buf[..., :cout]
+        la = ops.conv2d_launch([_nhwc(x)], wp, sc, sh, out, kh=1, kw=1, cout=cout, act=act, res=_nhwc(r) if res else None, tile=tile)
+        la.run()
+        assert la.kernel.startswith("pw_conv_kernel" if tile == 1 else "igemm_conv_kernel"), la.kernel
+        assert torch.isnan(buf[..., cout:]).all()
+        outs[tile] = out.clone()
+        _close(out.permute(0, 3, 1, 2), ref)
+    assert torch.equal(outs[1], outs[64064])
+    with pytest.raises(_lib.CenterposeHipError):                   # 3x3: not this kernel's shape
+        w3 = ops.pack_conv_weight(torch.randn(64, cin, 3, 3).cuda())
+        ops.conv2d([_nhwc(x)], w3, *ops.fold_bn(64, None, torch.zeros(64).cuda()), torch.empty(B, H, W, 64, device="cuda"), kh=3, kw=3, pad=1, cout=64, tile=1)
+    with pytest.raises(_lib.CenterposeHipError):                   # K = 128: measured, did not pay, not built in
+        x2 = torch.randn(B, H, W, 128, device="cuda")
+        ops.conv2d([x2], ops.pack_conv_weight(torch.randn(64, 128, 1, 1).cuda()), *ops.fold_bn(64, None, torch.zeros(64).cuda()),
+                   torch.empty(B, H, W, 64, device="cuda"), kh=1, kw=1, cout=64, tile=1)
+    auto = ops.conv2d_launch([_nhwc(x)], wp, sc, sh, torch.empty(B, H, W, cout, device="cuda"), kh=1, kw=1, cout=cout, act=act, res=_nhwc(r) if res else None)
+    auto.run()
+    assert auto.kernel.startswith("pw_conv_kernel")               # the default rule takes it for every eligible launch
+
+
 @pytest.mark.parametrize("xs,ws", [(1e30, 1e-30), (1e-30, 1e30), (3e18, 3e18), (1e-19, 1e-19)])
 def test_conv_split_bf16_magnitude_range(xs, ws):
     """the split-bf16 kernel's DOMAIN is finite operands below 2^127 (conv_igemm_bf16x3.hip header): across 60 binades of

@@ -8,7 +8,7 @@ dominant kernel."""
 import csv, glob, json, os, re, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-FAMILY = (("dcn_igemm_kernel", "cp_dcn_v2_f32"), ("conv3x3_wino", "cp_conv3x3_winograd_f32"), ("igemm_conv_kernel", "cp_conv2d_f32"),
+FAMILY = (("dcn_igemm_kernel", "cp_dcn_v2_f32"), ("conv3x3_wino", "cp_conv3x3_winograd_f32"), ("igemm_conv_kernel", "cp_conv2d_f32"), ("pw_conv_kernel", "cp_conv2d_f32"),
           ("conv3x3_patch_kernel", "cp_conv2d_f32"), ("conv3x3_c16_kernel", "cp_conv2d_f32"), ("stem7x7_kernel", "cp_stem7x7_f32"), ("stem7x7_c16_kernel", "cp_stem7x7_f32"), ("head_fused", "cp_head_fused_f32"),
           ("maxpool_nhwc_kernel", "cp_maxpool2d_nhwc_f32"), ("dw_deconv_add_kernel", "cp_dw_deconv_add_nhwc_f32"), ("dw_deconv2_add_kernel", "cp_dw_deconv_add_nhwc_f32"),
           ("sum_up_kernel", "cp_sum_up_nhwc_f32"), ("nms_topk_kernel", "decode"), ("pose_assign_kernel", "decode"))
