@@ -270,6 +270,71 @@ extern "C" int cp_sum_up_nhwc_f32(int n, const float* const* src, const int* ld,
     return 0;
 }
 
+// Up to four INDEPENDENT up-sampling sums in one launch (round 6): an HRNet module ends with one such sum per output branch
+// (pose_higher_hrnet.py:224-235: y_i = relu(sum_j fuse_ij(x_j))), 7-12 us each for 10-39 MB -- launch-bound one by one, and every one of
+// them sits on the critical path between two modules.  Member k owns the blocks [first[k], first[k + 1]); a block is one 256-element
+// segment of one output row; per element the same loads and the same order of additions as sum_up_kernel (bit-identical).
+struct SumUpMember { SumUpArgs a; float* out; int outLd; EwRow r; int H, W, xblocks; };
+struct SumUpGroup { SumUpMember m[4]; int first[5]; int n, relu; };
+__global__ void sum_up_group_kernel(const SumUpGroup g)
+{
+    int t = blockIdx.x, k = 0;
+    while (k + 1 < g.n && t >= g.first[k + 1]) ++k;                    // scalar
+    const SumUpMember& m = g.m[k];
+    t -= g.first[k];
+    const int row = t / m.xblocks, e = (t - row * m.xblocks) * EW_THREADS + threadIdx.x;
+    if (e >= m.r.rowElems) return;
+    int x, c4;
+    ew_split(m.r, e, x, c4);
+    const int H = m.H, W = m.W;
+    const int b = row / H, y = row - b * H;                              // uniform
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < m.a.n; ++j) {
+        const int sh = m.a.sh[j], hs = H >> sh, ws = W >> sh;
+        const float4 v = *reinterpret_cast<const float4*>(m.a.src[j] + ((size_t)(b * hs + (y >> sh)) * ws + (x >> sh)) * m.a.ld[j] + c4 * 4);
+        if (j == 0) acc = v;
+        else { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    }
+    if (g.relu) { acc.x = fmaxf(acc.x, 0.f); acc.y = fmaxf(acc.y, 0.f); acc.z = fmaxf(acc.z, 0.f); acc.w = fmaxf(acc.w, 0.f); }
+    *reinterpret_cast<float4*>(m.out + ((size_t)row * W + x) * m.outLd + c4 * 4) = acc;
+}
+
+// n <= 4 members; src: 4 pointers per member (NULL beyond its nsrc); meta: 14 ints per member = nsrc, ld[4], shift[4], outLd, B, H, W, C
+extern "C" int cp_sum_up_group_nhwc_f32(int n, const float* const* src, const int* meta, float* const* out, int relu, void* stream)
+{
+    CP_CHECK_ARG(n >= 1 && n <= 4 && src && meta && out, "sum_up_group: 1..4 members (got %d)", n);
+    SumUpGroup g;
+    g.n = n; g.relu = relu;
+    long long total = 0;
+    for (int k = 0; k < 4; ++k) {
+        const int kk = k < n ? k : 0;                                    // unused slots repeat member 0 (never indexed)
+        const int* mt = meta + 14 * kk;
+        SumUpMember& m = g.m[k];
+        const int ns = mt[0], B = mt[10], H = mt[11], W = mt[12], C = mt[13];
+        if (k < n) {
+            CP_CHECK_ARG(ns >= 1 && ns <= 4 && out[k] && C > 0 && C % 4 == 0 && mt[9] % 4 == 0, "sum_up_group: member %d: bad arguments", k);
+            CP_CHECK_ARG((long long)W * (C / 4) * (C / 4) < (1ll << 32) && (long long)B * H < (1ll << 31), "sum_up_group: member %d: row too large", k);
+        }
+        for (int i = 0; i < 4; ++i) {
+            m.a.src[i] = i < ns ? src[4 * kk + i] : nullptr; m.a.ld[i] = i < ns ? mt[1 + i] : 0; m.a.sh[i] = i < ns ? mt[5 + i] : 0;
+            if (k < n && i < ns) CP_CHECK_ARG(m.a.src[i] && m.a.ld[i] % 4 == 0, "sum_up_group: member %d source %d", k, i);
+        }
+        m.a.n = ns;
+        m.out = out[kk]; m.outLd = mt[9]; m.H = H; m.W = W;
+        m.r = ew_row(B * H, W, C / 4);
+        m.xblocks = (m.r.rowElems + EW_THREADS - 1) / EW_THREADS;
+        g.first[k] = (int)total;
+        if (k < n) total += (long long)m.r.rows * m.xblocks;
+    }
+    g.first[4] = (int)total;
+    for (int k = n; k < 4; ++k) g.first[k] = (int)total;
+    CP_CHECK_ARG(total > 0 && total < (1ll << 31), "sum_up_group: grid %lld", total);
+    hipLaunchKernelGGL(sum_up_group_kernel, dim3((unsigned)total), dim3(EW_THREADS), 0, (hipStream_t)stream, g);
+    cp_note_kernel("sum_up_group_kernel");
+    CP_CHECK_LAUNCH("sum_up_group_kernel");
+    return 0;
+}
+
 // ---- layout transforms (32x32 LDS tile transpose over (C, HW)) -------------------------------
 __global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C, int HW, int outLd, int cOff)
 {

@@ -26,6 +26,7 @@ int cp_stem7x7_f32(const float*, const float*, const float*, const float*, float
 int cp_maxpool2d_nhwc_f32(const float*, int, float*, int, int, int, int, int, int, int, int, void*);
 int cp_dw_deconv_add_nhwc_f32(const float*, int, const float*, const float*, int, float*, int, int, int, int, int, int, void*);
 int cp_sum_up_nhwc_f32(int, const float* const*, const int*, const int*, float*, int, int, int, int, int, int, void*);
+int cp_sum_up_group_nhwc_f32(int, const float* const*, const int*, float* const*, int, void*);
 int cp_head3x3_1x1_f32(const cp_conv_desc*, const float*, const float*, const float*, const float*, const float*, const float*, float*, int,
                        int, int, void*);
 int cp_dwconv2d_nhwc_f32(const float*, int, const float*, const float*, const float*, float*, int, int, int, int, int, int, int, int, int, void*);
@@ -45,7 +46,7 @@ int cp_decode_assign_f32(const float*, const float*, const float*, const float*,
 namespace {
 
 enum { FN_CONV = 1, FN_WINO = 2, FN_DCN = 3, FN_STEM7 = 4, FN_POOL = 5, FN_UPADD = 6, FN_SUMUP = 7, FN_DWCONV = 8, FN_AVGPOOL = 9,
-       FN_SCALEADD = 10, FN_SHUFFLE = 11, FN_HEAD = 12, FN_TOPK = 13, FN_ASSIGN = 14, FN_SPLITK = 15, FN_WINO24G = 16, FN_CONVG = 17 };   // ops.FN_IDS
+       FN_SCALEADD = 10, FN_SHUFFLE = 11, FN_HEAD = 12, FN_TOPK = 13, FN_ASSIGN = 14, FN_SPLITK = 15, FN_WINO24G = 16, FN_CONVG = 17, FN_SUMUPG = 18 };   // ops.FN_IDS
 enum { REF_NULL = 0, REF_BUF = 1, REF_CONST = 2 };
 
 struct Op {
@@ -135,6 +136,8 @@ int run_op(const Op& o, hipStream_t s)
         case FN_SUMUP:
             return cp_sum_up_nhwc_f32(I[0], reinterpret_cast<const float* const*>(P.data()), I + 1, I + 5, P[4], I[9], I[10], I[11], I[12],
                                       I[13], I[14], s);
+        case FN_SUMUPG:       // ptrs: src x16 (4 per member), out x4, (the storage all outputs live in); ints: n, relu, 14 per member (x4)
+            return cp_sum_up_group_nhwc_f32(I[0], reinterpret_cast<const float* const*>(P.data()), I + 2, reinterpret_cast<float* const*>(P.data() + 16), I[1], s);
         case FN_HEAD:
             return cp_head3x3_1x1_f32(reinterpret_cast<const cp_conv_desc*>(o.desc.data()), P[0], P[1], P[2], P[3], P[4], P[5], P[6], I[0], I[1],
                                       I[2], s);
@@ -170,6 +173,7 @@ bool arity_ok(const Op& o)
         case FN_POOL: return o.ptrs.size() == 2 && o.ints.size() == 9;
         case FN_UPADD: return o.ptrs.size() == 4 && o.ints.size() == 8;
         case FN_SUMUP: return o.ptrs.size() == 5 && o.ints.size() == 15;
+        case FN_SUMUPG: return o.ptrs.size() == 21 && o.ints.size() == 58 && o.ints[0] >= 1 && o.ints[0] <= 4;
         case FN_HEAD: return o.ptrs.size() == 7 && o.ints.size() == 3 && (int)o.desc.size() == cp_sizeof_conv_desc();
         case FN_DWCONV: return o.ptrs.size() == 5 && o.ints.size() == 10;
         case FN_AVGPOOL: return o.ptrs.size() == 2 && o.ints.size() == 5;

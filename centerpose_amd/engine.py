@@ -422,6 +422,27 @@ class PlanBuilder(nets.Graph):
         self.add("sum", "fuse", 0, ops.sum_up_launch([a.t for a in xs], shifts, out.t, relu))
         return out
 
+    def emit_sum_up_batch(self, members, relu):
+        """The per-branch sums that end an HRNet module as ONE launch (CP_GROUP=0 / CP_SUM_GROUP=0: one launch each).  Launched one by
+        one they are 7-12 us for 10-39 MB each and sit on the critical path between two modules; all outputs of the launch live in ONE
+        pool slot (`Engine.dependencies` tracks one output storage per launch record).  Bit-identical to the single launches."""
+        ok = os.environ.get("CP_GROUP", "1") != "0" and os.environ.get("CP_SUM_GROUP", "1") != "0" and 2 <= len(members) <= 4 and \
+            all(len(xs) <= 4 and not any(a.split for a in xs) for xs, _ in members)
+        if not ok:
+            return super().emit_sum_up_batch(members, relu)
+        sizes = [self.B * xs[0].H * xs[0].W * xs[0].t.shape[3] for xs, _ in members]
+        slot = self.pool.take(sum(sizes))
+        holder = Act(1, 1, 1, slot)
+        weakref.finalize(holder, self.pool.give, slot)          # the slot returns to the pool when the last member activation is dropped
+        outs, recs, off = [], [], 0
+        for (xs, shifts), n in zip(members, sizes):
+            out = Act(xs[0].H, xs[0].W, xs[0].C, slot[off:off + n].view(self.B, xs[0].H, xs[0].W, xs[0].t.shape[3]), parent=holder)
+            off += n
+            recs.append(([a.t for a in xs], shifts, out.t))
+            outs.append(out)
+        self.add("sum", "group:fuse", 0, ops.sum_up_group_launch(recs, slot[:off], relu))
+        return outs
+
     def emit_head(self, feat, p, hc):
         """Per head: [3x3 conv + bias + ReLU] -> ONE shared mid buffer -> 1x1 conv writing the reference's
         NCHW output (hm / hm_hp get their sigmoid, multi_pose.py:35-37, in the epilogue).  Running each
@@ -809,7 +830,7 @@ class Engine:
         """Algorithmic (compulsory) HBM bytes of every launch: each tensor argument once -- inputs, residual, the weights
         the kernel actually reads (Winograd launches carry U, not the direct weights), output."""
         # (a grouped launch lists every member's output AND the storage they all live in: the latter is not counted again)
-        grouped = ("cp_conv3x3_winograd24_group_f32", "cp_conv2d_group_f32")
+        grouped = ("cp_conv3x3_winograd24_group_f32", "cp_conv2d_group_f32", "cp_sum_up_group_nhwc_f32")
         return [sum(4 * t.numel() for t in (launch.tensors[:-1] if launch.fn in grouped else launch.tensors) if t is not None)
                 for _, _, _, launch in (self.launches if launches is None else launches)]
 

@@ -85,6 +85,11 @@ class Graph:
     def emit_sum_up(self, xs, shifts, relu):
         return Act(xs[0].H, xs[0].W, xs[0].C)
 
+    def emit_sum_up_batch(self, members, relu):
+        """members: [(xs, shifts)] -- INDEPENDENT up-sampling sums that may run as one launch (the per-branch sums that end an HRNet
+        module).  Default: one after the other."""
+        return [self.emit_sum_up(xs, shifts, relu) for xs, shifts in members]
+
     def emit_head(self, feat, p, hc):
         return None
 
@@ -319,12 +324,9 @@ class Graph:
             res = self.emit_conv_batch([(cur[ij],) + tuple(chains[ij][lvl][q] for q in (0, 1, 3, 4, 5, 6, 7)) for ij in todo])
             for ij, r in zip(todo, res):
                 cur[ij] = r
-        outs = []
-        for i in range(nout):
-            terms = [xs[j] if j == i else cur[(i, j)] for j in range(nb)]
-            shifts = [j - i if j > i else 0 for j in range(nb)]
-            outs.append(self.emit_sum_up(terms, shifts, True))
-        return outs
+        # y_i = relu(sum_j fuse_ij(x_j)) for every output branch (pose_higher_hrnet.py:224-235): independent of each other -> one batch
+        return self.emit_sum_up_batch([([xs[j] if j == i else cur[(i, j)] for j in range(nb)], [j - i if j > i else 0 for j in range(nb)])
+                                       for i in range(nout)], True)
 
     def hrnet_w32(self, x, p="backbone_model"):
         x = self.conv(x, p + ".conv1", p + ".bn1", 64, 3, 2, 1, relu=True, stem=True)

@@ -98,6 +98,11 @@ def marshal(fn, desc, ptrs, ints):
         lds = (ctypes.c_int * 4)(*ints[1:5])
         shs = (ctypes.c_int * 4)(*ints[5:9])
         return [ints[0], srcs, lds, shs, ptrs[4]] + ints[9:]
+    if fn == "cp_sum_up_group_nhwc_f32":          # ptrs: src x16 (4 per member), out x4, whole; ints: n, relu, 14 per member (x4)
+        srcs = (ctypes.c_void_p * 16)(*[p.value for p in ptrs[:16]])
+        outs = (ctypes.c_void_p * 4)(*[p.value for p in ptrs[16:20]])
+        meta = (ctypes.c_int * 56)(*ints[2:58])
+        return [ints[0], srcs, meta, outs, ints[1]]
     if fn == "cp_dwconv2d_nhwc_f32":              # ptrs: in, w, scale, shift, out; ints: inLd, outLd, B, H, W, C, k, s, p, act
         return [ptrs[0], ints[0], ptrs[1], ptrs[2], ptrs[3], ptrs[4]] + ints[1:]
     if fn == "cp_global_avgpool_nhwc_f32":        # ptrs: in, out; ints: inLd, outLd, B, HW, C
@@ -118,7 +123,8 @@ def marshal(fn, desc, ptrs, ints):
 FN_IDS = {"cp_conv2d_f32": 1, "cp_conv3x3_winograd_f32": 2, "cp_dcn_v2_f32": 3, "cp_stem7x7_f32": 4,
           "cp_maxpool2d_nhwc_f32": 5, "cp_dw_deconv_add_nhwc_f32": 6, "cp_sum_up_nhwc_f32": 7, "cp_dwconv2d_nhwc_f32": 8,
           "cp_global_avgpool_nhwc_f32": 9, "cp_scale_add_nhwc_f32": 10, "cp_shuffle_concat_nhwc_f32": 11, "cp_head3x3_1x1_f32": 12,
-          "cp_decode_topk_f32": 13, "cp_decode_assign_f32": 14, "cp_splitk_reduce_f32": 15, "cp_conv3x3_winograd24_group_f32": 16, "cp_conv2d_group_f32": 17}
+          "cp_decode_topk_f32": 13, "cp_decode_assign_f32": 14, "cp_splitk_reduce_f32": 15, "cp_conv3x3_winograd24_group_f32": 16, "cp_conv2d_group_f32": 17,
+          "cp_sum_up_group_nhwc_f32": 18}
 
 
 def pad_rows(t, ldw):
@@ -618,6 +624,25 @@ def sum_up_launch(srcs, shifts, out, relu):
     n = len(srcs)
     return Launch("cp_sum_up_nhwc_f32", None, list(srcs) + [None] * (4 - n) + [out],
                   [n] + [_ld(s) for s in srcs] + [0] * (4 - n) + list(shifts) + [0] * (4 - n) + [_ld(out), B, H, W, C, 1 if relu else 0])
+
+
+def sum_up_group_launch(members, whole, relu):
+    """Up to four independent up-sampling sums in ONE launch (the per-branch sums that end an HRNet module).  members: list of
+    (srcs, shifts, out); `whole`: the one storage every `out` is a view of (what the dependency tracking sees as this launch's output)."""
+    n = len(members)
+    assert 1 <= n <= 4
+    ptrs, outs, meta = [], [], []
+    for srcs, shifts, out in members:
+        B, H, W, C = out.shape
+        k = len(srcs)
+        assert 1 <= k <= 4 and out.untyped_storage().data_ptr() == whole.untyped_storage().data_ptr()
+        ptrs += list(srcs) + [None] * (4 - k)
+        outs.append(out)
+        meta += [k] + [_ld(t) for t in srcs] + [0] * (4 - k) + list(shifts) + [0] * (4 - k) + [_ld(out), B, H, W, C]
+    ptrs += [None] * (4 * (4 - n))
+    outs += [None] * (4 - n)
+    meta += [0] * (14 * (4 - n))
+    return Launch("cp_sum_up_group_nhwc_f32", None, ptrs + outs + [whole], [n, 1 if relu else 0] + meta)
 
 
 def sum_up(srcs, shifts, out, relu):

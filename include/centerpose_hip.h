@@ -169,6 +169,10 @@ int cp_dw_deconv_add_nhwc_f32(const float* in, int inLd, const float* w, const f
 /* HRNet fuse: out = relu?( sum_i nearest_upsample(src_i, 2^shift_i) ) (pose_higher_hrnet.py:217-235) */
 int cp_sum_up_nhwc_f32(int n, const float* const* src, const int* ld, const int* shift, float* out, int outLd, int B, int H,
                        int W, int C, int relu, void* stream);
+/* Up to four INDEPENDENT sums of that kind in ONE launch (the y_i = relu(sum_j fuse_ij(x_j)) of every output branch of an HRNet module,
+ * pose_higher_hrnet.py:224-235); bit-identical to the single launches.  src: 4 pointers per member (NULL beyond its source count);
+ * meta: 14 ints per member = nsrc, ld[4], shift[4], outLd, B, H, W, C; out: one NHWC output per member (they must not alias). */
+int cp_sum_up_group_nhwc_f32(int n, const float* const* src, const int* meta, float* const* out, int relu, void* stream);
 /* depthwise k x k conv + folded BN + activation (groups == channels): MobileNetV3 Block.conv2 (mobilenetv3.py:119-121, k 3 / 5,
  * stride 1 / 2) and ShuffleNetV2 banch1 / banch2 (shufflenetv2_dcn.py:67-88); w: [k*k][C], scale / shift: [C] */
 int cp_dwconv2d_nhwc_f32(const float* in, int inLd, const float* w, const float* scale, const float* shift, float* out, int outLd,

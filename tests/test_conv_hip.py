@@ -427,6 +427,45 @@ def test_sum_up():
     _close(out.permute(0, 3, 1, 2), ref, 1e-6)
 
 
+@pytest.mark.parametrize("nmem", [2, 3, 4])
+def test_sum_up_group_equals_single_launches(nmem):
+    """cp_sum_up_group_nhwc_f32 (round 6): the per-branch sums that end an HRNet module (pose_higher_hrnet.py:224-235, y_i = relu(sum_j
+    fuse_ij(x_j))) as ONE launch -- members of different sizes, source counts and up-sampling factors, odd map sizes, channel-padded
+    views -- BIT-IDENTICAL to one cp_sum_up_nhwc_f32 launch per member, and against torch."""
+    from centerpose_amd import ops
+    g = torch.Generator().manual_seed(nmem)
+    B = 2
+    shapes = [(32, 24, 20), (64, 12, 10), (128, 6, 5), (256, 3, 3)][:nmem]          # (C, H, W) of the branches
+    members, refs = [], []
+    total = sum(B * H * W * C for C, H, W in shapes)
+    whole = torch.full((total,), float("nan"), device="cuda")
+    off = 0
+    for i, (C, H, W) in enumerate(shapes):
+        srcs, shifts, ref = [], [], 0
+        for j in range(nmem):                       # a term per branch: same size (j <= i) or 2^(j - i) times smaller (j > i)
+            sh = j - i if j > i else 0
+            if (H >> sh) == 0 or (W >> sh) == 0 or H % (1 << sh) or W % (1 << sh):
+                continue
+            t = torch.randn(B, C, H >> sh, W >> sh, generator=g)
+            ref = ref + (F.interpolate(t, scale_factor=1 << sh, mode="nearest") if sh else t)
+            wide = torch.randn(B, H >> sh, W >> sh, C + 16, generator=g).cuda()     # a view with a larger pixel stride
+            wide[..., :C] = _nhwc(t)
+            srcs.append(wide[..., :C] if j % 2 else _nhwc(t))
+            shifts.append(sh)
+        out = whole[off:off + B * H * W * C].view(B, H, W, C)
+        off += B * H * W * C
+        members.append((srcs, shifts, out))
+        refs.append(F.relu(ref))
+    la = ops.sum_up_group_launch(members, whole, True)
+    la.run()
+    assert la.kernel == "sum_up_group_kernel" and not torch.isnan(whole).any()
+    for (srcs, shifts, out), ref in zip(members, refs):
+        _close(out.permute(0, 3, 1, 2), ref, 1e-6)
+        single = torch.empty_like(out)
+        ops.sum_up(srcs, shifts, single, True)
+        assert torch.equal(single, out)
+
+
 @pytest.mark.parametrize("C,k,stride,act", [(16, 3, 1, 0), (72, 5, 2, 1), (64, 3, 2, 3), (240, 5, 1, 3), (24, 3, 1, 4)])
 def test_dwconv_bn_act(C, k, stride, act):
     """depthwise k x k + folded BN + {none, relu, h-swish, h-sigmoid} vs torch (mobilenetv3.py:119-121, shufflenetv2_dcn.py:67-88)."""
