@@ -115,7 +115,7 @@ class BackBoneWithHead:
         tails of the other) and yields `(outputs, dets)` per batch IN ORDER -- per batch bit-identical to `process(batch)`.
         `dets` is a fresh tensor as in `process`; `outputs` are the static buffers of the instance that ran the batch, valid until
         the generator is advanced past the current group of `depth` results.  The trade: a batch's result is available only when
-        its whole group has run (latency ~ depth x), throughput rises (MI355X: +3 % dla_34 B=16, +13 % res_50 B=8, +27 % hrnet
+        its whole group has run (latency ~ depth x), throughput rises (MI355X: +2.5 % dla_34 B=16, +11 % res_50 B=8, +27 % hrnet
         B=8 at depth 2).  A last group of fewer than `depth` batches, batches whose shape differs inside a group (FIX_RES =
         false) and depth <= 1 run through `process`, one replay each.  No host synchronisation anywhere.
         The reference has no counterpart: it runs one image at a time, synchronously (lib/detectors/base_detector.py:79-140,
